@@ -1,0 +1,302 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels
+to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+
+What it does: registers empty stand-in modules for the
+optional imports the hot path never touches (configargparse -> argparse,
+face_alignment, imageio, natsort, cv2, tensorboard), makes ``Tensor.cuda`` a
+no-op, supplies the flags through ``sys.argv`` before import (the reference
+parses them at import time), then calls the reference's own functions on seeded
+inputs and stores inputs + outputs as small ``.npz`` fixtures next to this file.
+
+Weights are NOT stored: both this script and the tests rebuild them from
+``oracle.xavier_facenerf_params(seed, dims)`` (numpy RandomState, Xavier-uniform,
+bias 0.01 as audio_exp_nerf.py:442-448), optionally with the sigma head scaled
+(``sigma_gain``) so the volume is not empty.
+
+The torso variant's extra output (``rgb_map_fg``, TorsoNeRF/run_nerf.py:757) is
+pinned at formula level only: that module's import chain is stale upstream
+(SURVEY.md section 2), so the fixture applies the one-line formula to weights and
+colours produced by the HeadNeRF reference functions.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+
+NEAR, FAR = 0.5772005200386048, 1.1772005200386046
+
+
+def install_shims():
+    class _CfgParser(argparse.ArgumentParser):
+        def add_argument(self, *a, **k):
+            k.pop("is_config_file", None)
+            return super().add_argument(*a, **k)
+
+    m = types.ModuleType("configargparse")
+    m.ArgumentParser = _CfgParser
+    sys.modules["configargparse"] = m
+    for name in ("face_alignment", "imageio", "cv2"):
+        sys.modules[name] = types.ModuleType(name)
+    ns = types.ModuleType("natsort")
+    ns.natsorted = sorted
+    sys.modules["natsort"] = ns
+    tb = types.ModuleType("torch.utils.tensorboard")
+
+    class SummaryWriter:  # no-op
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, _):
+            return lambda *a, **k: None
+
+    tb.SummaryWriter = SummaryWriter
+    sys.modules["torch.utils.tensorboard"] = tb
+    sys.modules["tensorboard"] = types.ModuleType("tensorboard")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def load_state(module, params):
+    module.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+
+
+def scale_sigma(params, gain, bias):
+    p = {k: v.clone() for k, v in params.items()}
+    p["alpha_linear.weight"] = p["alpha_linear.weight"] * gain
+    p["alpha_linear.bias"] = torch.full_like(p["alpha_linear.bias"], bias)
+    return p
+
+
+def main():
+    install_shims()
+    sys.argv = [sys.argv[0], "--perturb", "0", "--dim_aud", "64", "--dim_expr", "76",
+                "--N_samples", "64", "--N_importance", "128", "--near", str(NEAR), "--far", str(FAR),
+                "--vis_path", "/tmp/idealnerf_golden_vis", "--chunk", "512"]
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    import oracle  # only for weight construction + synthetic inputs (no oracle output is stored)
+    from models.face_nerf import FaceNeRF
+    import NeRFs.HeadNeRF.helper as helper
+    from NeRFs.HeadNeRF.train import baseline
+    from NeRFs.HeadNeRF.train import audio_exp_nerf as aen
+
+    rs = np.random.RandomState(1234)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    out = {}
+
+    # ---- a2: positional encoding -------------------------------------------------
+    x = f32(rs.uniform(-1.2, 1.2, size=(256, 3)))
+    e10, d10 = helper.get_embedder(10, 0)
+    e4, d4 = helper.get_embedder(4, 0)
+    e3, d3 = helper.get_embedder(3, 0)
+    np.savez(os.path.join(HERE, "pe.npz"), x=x.numpy(), pe10=e10(x).numpy(), pe4=e4(x).numpy(),
+             pe3=e3(x).numpy())
+    assert (d10, d4, d3) == (63, 27, 21)
+
+    # ---- a5: FaceNeRF, C in {235, 169, 127} ---------------------------------------
+    variants = {"c235": dict(dim_aud=64, dim_expr=76, dim_latent=32),
+                "c169": dict(dim_aud=106, dim_expr=0, dim_latent=0),
+                "c127": dict(dim_aud=64, dim_expr=0, dim_latent=0)}
+    fx = {}
+    for name, v in variants.items():
+        dims = oracle.facenerf_dims(**v)
+        params = oracle.xavier_facenerf_params(11, dims)
+        net = FaceNeRF(D=8, W=256, input_ch=63, input_ch_views=27, dim_aud=v["dim_aud"],
+                       dim_latent=v["dim_latent"], dim_expr=v["dim_expr"], skips=[4])
+        assert {k: tuple(t.shape) for k, t in net.state_dict().items()} == oracle.facenerf_param_shapes(dims)
+        load_state(net, params)
+        pts = f32(rs.uniform(-1.0, 1.0, size=(512, 3)))
+        dirs = f32(rs.standard_normal((512, 3)))
+        dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+        xin = torch.cat([e10(pts), e4(dirs)], -1)
+        aud = f32(rs.standard_normal(v["dim_aud"]))
+        expr = f32(rs.standard_normal(v["dim_expr"])) if v["dim_expr"] else None
+        lat = f32(rs.standard_normal(v["dim_latent"])) if v["dim_latent"] else None
+        with torch.no_grad():
+            y = net(xin, aud, expr, lat)
+        fx[name + "_x"] = xin.numpy()
+        fx[name + "_aud"] = aud.numpy()
+        if expr is not None:
+            fx[name + "_expr"] = expr.numpy()
+        if lat is not None:
+            fx[name + "_latent"] = lat.numpy()
+        fx[name + "_out"] = y.numpy()
+    np.savez(os.path.join(HERE, "facenerf.npz"), **fx)
+
+    # ---- a6: raw2outputs, S in {64, 192} -----------------------------------------
+    fx = {}
+    for S in (64, 192):
+        n = 64
+        raw = f32(rs.standard_normal((n, S, 4)))
+        raw[..., 3] = raw[..., 3] * 40.0  # mix of empty and dense samples
+        z = torch.sort(f32(rs.uniform(NEAR, FAR, size=(n, S))), dim=-1)[0]
+        d = f32(rs.standard_normal((n, 3)))
+        bc = f32(rs.uniform(0, 1, size=(n, 3)))
+        with torch.no_grad():
+            rgb_map, disp, acc, w, depth = baseline.raw2outputs(raw, z, d, bc)
+            rgb = torch.sigmoid(raw[..., :3])
+            rgb_fg = torch.sum(w[:, :-1, None] * rgb[:, :-1, :], -2)  # TorsoNeRF/run_nerf.py:757 (formula level)
+        fx.update({f"s{S}_raw": raw.numpy(), f"s{S}_z": z.numpy(), f"s{S}_d": d.numpy(), f"s{S}_bc": bc.numpy(),
+                   f"s{S}_rgb_map": rgb_map.numpy(), f"s{S}_disp": disp.numpy(), f"s{S}_acc": acc.numpy(),
+                   f"s{S}_weights": w.numpy(), f"s{S}_depth": depth.numpy(), f"s{S}_rgb_fg": rgb_fg.numpy()})
+    np.savez(os.path.join(HERE, "raw2outputs.npz"), **fx)
+
+    # ---- a7: sample_pdf, capturing cdf + inds at the searchsorted boundary ---------
+    captured = {}
+    real_ss = torch.searchsorted
+
+    def spy(cdf, u, **kw):
+        r = real_ss(cdf, u, **kw)
+        captured["cdf"], captured["u"], captured["inds"] = cdf.clone(), u.clone(), r.clone()
+        return r
+
+    fx = {}
+    n = 64
+    z = torch.sort(f32(rs.uniform(NEAR, FAR, size=(n, 64))), dim=-1)[0]
+    bins = 0.5 * (z[:, 1:] + z[:, :-1])
+    w = f32(rs.uniform(0, 1, size=(n, 62))) ** 4
+    w[:8] = 0.0          # empty rays: pdf uniform, denom guard
+    w[8:16, 5:] = 0.0    # mass concentrated at the front
+    torch.searchsorted = spy
+    try:
+        with torch.no_grad():
+            zs_det = helper.sample_pdf(bins, w, 128, det=True)
+        fx.update(bins=bins.numpy(), weights=w.numpy(), det_cdf=captured["cdf"].numpy(),
+                  det_u=captured["u"].numpy(), det_inds=captured["inds"].numpy(), det_samples=zs_det.numpy())
+        with torch.no_grad():
+            zs_rnd = helper.sample_pdf(bins, w, 128, det=False, pytest=True)  # numpy seed 0 u
+        fx.update(rnd_cdf=captured["cdf"].numpy(), rnd_u=captured["u"].numpy(),
+                  rnd_inds=captured["inds"].numpy(), rnd_samples=zs_rnd.numpy())
+    finally:
+        torch.searchsorted = real_ss
+    np.savez(os.path.join(HERE, "sample_pdf.npz"), **fx)
+
+    # ---- a3-a9: Network.render_rays (+ a1/a9 full-frame harness, a12 train harness) --
+    dims = oracle.facenerf_dims()
+    H = W = 32
+    syn = oracle.synthetic_frame(H, W, seed=0, dims=dims)
+    net = aen.Network(H, W, syn["focal"], NEAR, FAR, 512, None, 64, 128)
+    pc = scale_sigma(oracle.xavier_facenerf_params(2, dims), 300.0, 0.3)
+    pf = scale_sigma(oracle.xavier_facenerf_params(3, dims), 300.0, 0.3)
+    load_state(net.face_nerf_coarse, pc)
+    load_state(net.face_nerf_fine, pf)
+    net.eval()
+
+    ro, rd = helper.get_rays(H, W, syn["focal"], syn["c2w"])
+    taps = {}
+    real_r2o, real_sp = aen.raw2outputs, aen.sample_pdf
+
+    def tap_r2o(raw, z_vals, rays_d, bc_rgb, *a, **k):
+        r = real_r2o(raw, z_vals, rays_d, bc_rgb, *a, **k)
+        tag = "coarse" if raw.shape[1] == 64 else "fine"
+        taps.setdefault("raw_" + tag, []).append(raw.detach().clone())
+        taps.setdefault("z_" + tag, []).append(z_vals.detach().clone())
+        taps.setdefault("weights_" + tag, []).append(r[3].detach().clone())
+        return r
+
+    def tap_sp(bins, weights, N, det=False, pytest=False):
+        torch.searchsorted = spy
+        try:
+            r = real_sp(bins, weights, N, det=det, pytest=pytest)
+        finally:
+            torch.searchsorted = real_ss
+        taps.setdefault("cdf", []).append(captured["cdf"])
+        taps.setdefault("u", []).append(captured["u"])
+        taps.setdefault("inds", []).append(captured["inds"])
+        taps.setdefault("z_samples", []).append(r.detach().clone())
+        return r
+
+    aen.raw2outputs, aen.sample_pdf = tap_r2o, tap_sp
+    try:
+        # (i) full frame through render_dynamic_face (rays from the pose; chunk=512 -> 2 chunks)
+        with torch.no_grad():
+            rgb, disp, acc, last_w, extras = net.render_dynamic_face(
+                H, W, syn["focal"], expr=syn["expr"], poses=syn["c2w"], latent_code=syn["latent"],
+                render_poses=syn["c2w"][:3, :4], chunk=512, near=NEAR, far=FAR, rays=None, bc_rgb=syn["bc"],
+                aud_para=syn["aud"], ndc=False)
+        viewdirs = rd / torch.norm(rd, dim=-1, keepdim=True)
+        rays = torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), NEAR * torch.ones(H * W, 1),
+                          FAR * torch.ones(H * W, 1), viewdirs.reshape(-1, 3)], -1).float()
+        cat = lambda k: torch.cat(taps[k], 0).numpy()
+        fx = dict(rays=rays.numpy(), rgb=rgb.numpy(), disp=disp.numpy(), acc=acc.numpy(), last_weight=last_w.numpy(),
+                  rgb0=extras["rgb0"].numpy(), disp0=extras["disp0"].numpy(), acc0=extras["acc0"].numpy(),
+                  z_std=extras["z_std"].numpy(),
+                  tap_z_coarse=cat("z_coarse"), tap_weights_coarse=cat("weights_coarse"),
+                  tap_cdf=cat("cdf"), tap_u=cat("u")[:1], tap_inds=cat("inds").astype(np.int16),
+                  tap_z_samples=cat("z_samples"), tap_z_fine=cat("z_fine"),
+                  # the bulky per-sample taps only for the first 128 rays
+                  tap_raw_coarse=cat("raw_coarse")[:128], tap_raw_fine=cat("raw_fine")[:128],
+                  tap_weights_fine=cat("weights_fine")[:128])
+        np.savez_compressed(os.path.join(HERE, "frame32.npz"), **fx)
+
+        # (ii) 64 rays with the reference's numpy-seeded jitter (perturb=1, pytest=True)
+        taps.clear()
+        sel = torch.from_numpy(rs.choice(H * W, size=64, replace=False))
+        with torch.no_grad():
+            ret = net.render_rays(rays[sel], syn["bc"].reshape(-1, 3)[sel], syn["aud"], syn["c2w"], syn["latent"],
+                                  syn["expr"], perturb=1.0, pytest=True)
+        np.random.seed(0)
+        t_rand = np.random.rand(64, 64).astype(np.float32)  # what the reference drew (audio_exp_nerf.py:324-326)
+        fx = dict(sel=sel.numpy(), t_rand=t_rand, u=cat("u"), inds=cat("inds"), cdf=cat("cdf"),
+                  z_coarse=cat("z_coarse"), z_samples=cat("z_samples"), z_fine=cat("z_fine"),
+                  weights_coarse=cat("weights_coarse"), raw_coarse=cat("raw_coarse"), raw_fine=cat("raw_fine"),
+                  **{k: v.numpy() for k, v in ret.items()})
+        np.savez_compressed(os.path.join(HERE, "rays64_jitter.npz"), **fx)
+
+        # (iii) config 1: 256 rays, N_importance = 0 (render_rays directly; a9 KeyError path avoided)
+        taps.clear()
+        aen.args.N_importance = 0
+        sel0 = torch.from_numpy(rs.choice(H * W, size=256, replace=False))
+        with torch.no_grad():
+            ret0 = net.render_rays(rays[sel0], syn["bc"].reshape(-1, 3)[sel0], syn["aud"], syn["c2w"], syn["latent"],
+                                   syn["expr"])
+        aen.args.N_importance = 128
+        np.savez_compressed(os.path.join(HERE, "rays256_coarse_only.npz"), sel=sel0.numpy(),
+                            **{k: v.numpy() for k, v in ret0.items()})
+
+        # (iv) a12: one training step's loss + grads on 64 rays (perturb=0), autograd through the reference
+        taps.clear()
+        net.train()
+        for p_ in net.parameters():
+            p_.grad = None
+        aud = syn["aud"].clone().requires_grad_(True)
+        lat = syn["latent"].clone().requires_grad_(True)
+        tgt = f32(rs.uniform(0, 1, size=(64, 3)))
+        ret = net.render_rays(rays[sel], syn["bc"].reshape(-1, 3)[sel], aud, syn["c2w"], lat, syn["expr"])
+        img_loss = helper.img2mse(ret["rgb_map"], tgt)
+        loss = img_loss + helper.img2mse(ret["rgb0"], tgt) + 10 * (torch.norm(lat) * 0.0005)
+        loss.backward()
+        g = lambda m, k: dict(m.named_parameters())[k].grad.numpy()
+        fx = dict(sel=sel.numpy(), target=tgt.numpy(), loss=loss.detach().numpy(), img_loss=img_loss.detach().numpy(),
+                  rgb_map=ret["rgb_map"].detach().numpy(), rgb0=ret["rgb0"].detach().numpy(),
+                  g_aud=aud.grad.numpy(), g_latent=lat.grad.numpy())
+        for tag, m in (("c", net.face_nerf_coarse), ("f", net.face_nerf_fine)):
+            for k in ("pts_linears.0.weight", "pts_linears.0.bias", "pts_linears.5.weight", "pts_linears.7.weight",
+                      "views_linears.0.weight", "views_linears.2.bias", "alpha_linear.weight", "alpha_linear.bias",
+                      "rgb_linear.weight", "rgb_linear.bias"):
+                fx[f"g_{tag}_{k}"] = g(m, k)
+        np.savez_compressed(os.path.join(HERE, "train_step.npz"), **fx)
+    finally:
+        aen.raw2outputs, aen.sample_pdf = real_r2o, real_sp
+
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f"{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:8.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

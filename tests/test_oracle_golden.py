@@ -1,0 +1,163 @@
+"""Pin the CPU oracle against vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+NEAR, FAR = 0.5772005200386048, 1.1772005200386046
+
+
+def scale_sigma(p, gain=300.0, bias=0.3):
+    p = {k: v.clone() for k, v in p.items()}
+    p["alpha_linear.weight"] = p["alpha_linear.weight"] * gain
+    p["alpha_linear.bias"] = torch.full_like(p["alpha_linear.bias"], bias)
+    return p
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_positional_encoding(golden):
+    g = golden("pe")
+    x = T(g["x"])
+    for L, key in ((10, "pe10"), (4, "pe4"), (3, "pe3")):
+        out = oracle.positional_encoding(x, L).numpy()
+        assert out.shape == g[key].shape
+        np.testing.assert_array_equal(out, g[key])
+
+
+@pytest.mark.parametrize("name,v", [("c235", dict(dim_aud=64, dim_expr=76, dim_latent=32)),
+                                    ("c169", dict(dim_aud=106, dim_expr=0, dim_latent=0)),
+                                    ("c127", dict(dim_aud=64, dim_expr=0, dim_latent=0))])
+def test_facenerf(golden, name, v):
+    g = golden("facenerf")
+    dims = oracle.facenerf_dims(**v)
+    p = oracle.xavier_facenerf_params(11, dims)
+    opt = lambda k: T(g[k]) if k in g else None
+    y = oracle.facenerf_forward(p, T(g[name + "_x"]), T(g[name + "_aud"]), opt(name + "_expr"),
+                                opt(name + "_latent"), dims)
+    assert rel_err(y.numpy(), g[name + "_out"]) < 2e-6
+
+
+@pytest.mark.parametrize("S", [64, 192])
+def test_composite(golden, S):
+    g = golden("raw2outputs")
+    k = lambda n: T(g[f"s{S}_{n}"])
+    rgb, disp, acc, w, depth, fg = oracle.composite(k("raw"), k("z"), k("d"), k("bc"), with_fg=True)
+    np.testing.assert_array_equal(w.numpy(), g[f"s{S}_weights"])
+    np.testing.assert_array_equal(rgb.numpy(), g[f"s{S}_rgb_map"])
+    np.testing.assert_array_equal(disp.numpy(), g[f"s{S}_disp"])
+    np.testing.assert_array_equal(acc.numpy(), g[f"s{S}_acc"])
+    np.testing.assert_array_equal(depth.numpy(), g[f"s{S}_depth"])
+    np.testing.assert_array_equal(fg.numpy(), g[f"s{S}_rgb_fg"])
+
+
+@pytest.mark.parametrize("mode", ["det", "rnd"])
+def test_sample_importance(golden, mode):
+    g = golden("sample_pdf")
+    u = None if mode == "det" else T(g["rnd_u"])
+    z, inds, cdf, u_used = oracle.sample_importance(T(g["bins"]), T(g["weights"]), 128, det=(mode == "det"), u=u)
+    np.testing.assert_array_equal(u_used.numpy(), g[mode + "_u"])
+    np.testing.assert_array_equal(cdf.numpy(), g[mode + "_cdf"])
+    np.testing.assert_array_equal(inds.numpy(), g[mode + "_inds"])       # the bit-exact target
+    np.testing.assert_array_equal(z.numpy(), g[mode + "_samples"])
+    # the boundary on its own: golden (cdf, u) in -> golden inds out
+    z2, inds2 = oracle.invert_cdf(T(g[mode + "_cdf"]), T(g["bins"]), T(g[mode + "_u"]))
+    np.testing.assert_array_equal(inds2.numpy(), g[mode + "_inds"])
+    np.testing.assert_array_equal(z2.numpy(), g[mode + "_samples"])
+
+
+def _nets():
+    dims = oracle.facenerf_dims()
+    return dims, scale_sigma(oracle.xavier_facenerf_params(2, dims)), scale_sigma(oracle.xavier_facenerf_params(3, dims))
+
+
+def test_frame32(golden):
+    g = golden("frame32")
+    dims, pc, pf = _nets()
+    syn = oracle.synthetic_frame(32, 32, seed=0, dims=dims)
+    ro, rd = oracle.camera_rays(32, 32, syn["focal"], syn["c2w"])
+    rays = oracle.ray_records(ro, rd, NEAR, FAR)
+    np.testing.assert_array_equal(rays.numpy(), g["rays"])
+    with torch.no_grad():
+        out = oracle.render_frame(32, 32, syn["focal"], syn["c2w"], NEAR, FAR, syn["bc"], pc, pf, syn["aud"],
+                                  syn["expr"], syn["latent"], chunk=512, dims=dims, taps=True)
+    # same machine, same op sequence => the oracle reproduces the reference's index decisions exactly
+    np.testing.assert_array_equal(out["tap_inds"].reshape(1024, 128).numpy(), g["tap_inds"].astype(np.int64))
+    np.testing.assert_array_equal(out["tap_z_coarse"].reshape(1024, 64).numpy(), g["tap_z_coarse"])
+    for k, gk, tol in (("rgb_map", "rgb", 1e-6), ("disp_map", "disp", 1e-6), ("acc_map", "acc", 1e-6),
+                       ("last_weight", "last_weight", 1e-6), ("rgb0", "rgb0", 1e-6), ("z_std", "z_std", 1e-6),
+                       ("tap_weights_coarse", "tap_weights_coarse", 1e-6), ("tap_cdf", "tap_cdf", 1e-6),
+                       ("tap_z_fine", "tap_z_fine", 1e-6)):
+        assert rel_err(out[k].reshape(g[gk].shape).numpy(), g[gk]) < tol, k
+    # the frame is not empty: the volume contributes visibly more than the background alone
+    assert np.abs(g["rgb"].reshape(-1, 3) - syn["bc"].reshape(-1, 3).numpy()).mean() > 0.05
+
+
+def test_rays64_jitter(golden):
+    g = golden("rays64_jitter")
+    f = golden("frame32")
+    dims, pc, pf = _nets()
+    syn = oracle.synthetic_frame(32, 32, seed=0, dims=dims)
+    sel = T(g["sel"])
+    rays, bc = T(f["rays"])[sel], syn["bc"].reshape(-1, 3)[sel]
+    with torch.no_grad():
+        out = oracle.render_rays(rays, bc, pc, pf, syn["aud"], syn["expr"], syn["latent"], dims=dims,
+                                 t_rand=T(g["t_rand"]), u=T(g["u"]), taps=True)
+    np.testing.assert_array_equal(out["tap_z_coarse"].numpy(), g["z_coarse"])
+    np.testing.assert_array_equal(out["tap_inds"].numpy(), g["inds"])
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std", "last_weight"):
+        assert rel_err(out[k].numpy(), g[k]) < 1e-6, k
+    assert rel_err(out["tap_z_fine"].numpy(), g["z_fine"]) < 1e-6
+
+
+def test_rays256_coarse_only(golden):
+    g = golden("rays256_coarse_only")
+    f = golden("frame32")
+    dims, pc, _ = _nets()
+    syn = oracle.synthetic_frame(32, 32, seed=0, dims=dims)
+    sel = T(g["sel"])
+    with torch.no_grad():
+        out = oracle.render_rays(T(f["rays"])[sel], syn["bc"].reshape(-1, 3)[sel], pc, None, syn["aud"], syn["expr"],
+                                 syn["latent"], n_importance=0, dims=dims)
+    assert set(out) == {"rgb_map", "disp_map", "acc_map"}
+    for k in out:
+        assert rel_err(out[k].numpy(), g[k]) < 1e-6, k
+
+
+def test_train_step(golden):
+    g = golden("train_step")
+    f = golden("frame32")
+    dims, pc, pf = _nets()
+    syn = oracle.synthetic_frame(32, 32, seed=0, dims=dims)
+    sel = T(g["sel"])
+    for p in (pc, pf):
+        for v in p.values():
+            v.requires_grad_(True)
+    aud = syn["aud"].clone().requires_grad_(True)
+    lat = syn["latent"].clone().requires_grad_(True)
+    out = oracle.render_rays(T(f["rays"])[sel], syn["bc"].reshape(-1, 3)[sel], pc, pf, aud, syn["expr"], lat, dims=dims)
+    loss, img_loss = oracle.train_loss(out, T(g["target"]), lat)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    assert rel_err(aud.grad.numpy(), g["g_aud"]) < 1e-4
+    assert rel_err(lat.grad.numpy(), g["g_latent"]) < 1e-4
+    for tag, p in (("c", pc), ("f", pf)):
+        for k in ("pts_linears.0.weight", "pts_linears.5.weight", "views_linears.0.weight", "alpha_linear.weight",
+                  "rgb_linear.bias"):
+            assert rel_err(p[k].grad.numpy(), g[f"g_{tag}_{k}"]) < 1e-4, (tag, k)
+    assert pc["feature_linear.weight"].grad is None   # constructed, never used (face_nerf.py:34 vs :66)
+
+
+def test_torso_signal_shape():
+    syn = oracle.synthetic_frame(8, 8)
+    pose = torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
+    s = oracle.torso_signal(syn["aud"], pose)
+    assert s.shape == (64 + 42,)
+    e = oracle.pose_to_euler_trans(pose[None])
+    assert torch.allclose(e[0, 3:], syn["c2w"][:, 3])
