@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json configs[1] -- May HeadNeRF 512x512 full-frame
+render, N_sample=64 + N_importance=128, synthetic inputs.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one full frame through the hot path (ray generation -> coarse PE+MLP ->
+compositing -> inverse-CDF sampling -> fine PE+MLP -> compositing).  With N ranks the
+frame is split into N row bands (one per GPU) and the rendered tiles are all-gathered
+over RCCL, so total work is fixed: "strong" scaling.  Inputs are resident in HBM before
+the timed region.  value = ray-samples (MLP point evaluations, 256 per ray) per second,
+whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 1_114_368      # algorithmic, SURVEY.md section 8(d)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(syn, pc, pf, gpu_rgb_band, band_row0, n_rays=2048):
+    """The CPU oracle (a port of the reference's path, pinned to it by tests/golden) timed on
+    this host on a bounded sample: the first `n_rays` rays of the frame."""
+    import oracle
+    W = syn["W"]
+    nrows = (n_rays + W - 1) // W
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    kw = dict(chunk=1024)
+    with torch.no_grad():
+        oracle.render_frame(syn["H"], W, syn["focal"], syn["c2w"], syn["near"], syn["far"], syn["bc"], pc, pf,
+                            syn["aud"], syn["expr"], syn["latent"], rows=(0, 1), **kw)  # warm (512 rays)
+        t0 = time.perf_counter()
+        ref = oracle.render_frame(syn["H"], W, syn["focal"], syn["c2w"], syn["near"], syn["far"], syn["bc"], pc, pf,
+                                  syn["aud"], syn["expr"], syn["latent"], rows=(0, nrows), **kw)
+        dt = time.perf_counter() - t0
+    rays = nrows * W
+    out = {"value": rays * 256 / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"first {rays} rays ({nrows} rows) of the same 512x512 frame, 64+128 samples, "
+                     f"PyTorch-CPU oracle, 1 warm-up + 1 timed run ({dt:.1f} s)"}
+    psnr = None
+    if gpu_rgb_band is not None and band_row0 == 0 and gpu_rgb_band.shape[0] >= nrows:
+        mse = float(((gpu_rgb_band[:nrows].cpu() - ref["rgb_map"]) ** 2).mean())
+        psnr = 10.0 * torch.log10(torch.tensor(1.0 / max(mse, 1e-20))).item()
+    return out, psnr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--size", type=int, default=512)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import idealnerf_amd
+    from idealnerf_amd import ops, parallel, synthetic
+    from idealnerf_amd.helper import linspace01
+    lib = idealnerf_amd._lib.load()
+
+    H = W = args.size
+    S, Ni = 64, 128
+    syn = synthetic.frame(H, W, seed=0)
+    coarse = synthetic.xavier_state_dict(idealnerf_amd.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76), 2, 300.0, 0.3).to(dev)
+    fine = synthetic.xavier_state_dict(idealnerf_amd.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76), 3, 300.0, 0.3).to(dev)
+    g = lambda t: t.to(dev)
+    aud, expr, latent = g(syn["aud"]), g(syn["expr"]), g(syn["latent"])
+    r0, r1 = parallel.row_band(H, rank, world)
+    bc = syn["bc"][r0:r1].reshape(-1, 3).contiguous().to(dev)
+    t_vals, u = linspace01(S, dev), linspace01(Ni, dev)
+    pk_c, pk_f = coarse.packed_weights(), fine.packed_weights()
+
+    def step():
+        # per frame: pose -> rays, conditioning -> biases, then the per-ray path, then the tile exchange
+        rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0, device=dev)
+        fc = coarse.folded_bias(aud, expr, latent)
+        ff = fine.folded_bias(aud, expr, latent)
+        out = ops.render_rays_fwd(rays, bc, pk_c, fc, pk_f, ff, t_vals, u, Ni)
+        tile = out["rgb_map"].reshape(r1 - r0, W, 3)
+        return parallel.gather_rows(tile, H), tile
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        lib.idealnerf_profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frame, tile = step()
+        fence()
+        dt = time.perf_counter() - t0
+    import ctypes as C
+    k_ms, k_n, k_pts = C.c_double(), C.c_int64(), C.c_int64()
+    lib.idealnerf_profile_end(C.byref(k_ms), C.byref(k_n), C.byref(k_pts))
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        samples = H * W * (S + S + Ni) * args.steps
+        value = samples / dt
+        ach = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12 if k_ms.value > 0 else None
+        res = {
+            "metric": "ray-samples/sec (64+128 pts, 512x512), whole job", "value": value, "unit": "ray-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "per_gpu": value / world, "rays_per_s": value / (S + S + Ni),
+            "config": {"workload": f"BASELINE configs[1]: May HeadNeRF {H}x{W} full-frame render, N_sample=64 "
+                                   "N_importance=128, dim_aud=64 dim_expr=76 latent=32, perturb=0",
+                       "rays_per_step": H * W, "samples_per_ray": S + S + Ni,
+                       "partition": f"{world} row band(s) + RCCL all_gather of rgb tiles" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)",
+                         "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None, "traffic": None,
+                         "launches": k_n.value, "avg_launch_ms": (k_ms.value / k_n.value) if k_n.value else None,
+                         "flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": (k_pts.value / k_n.value) if k_n.value else None,
+                         "kernel_time_share": (k_ms.value * 1e-3) / dt if dt > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            pc = {k: v.detach().cpu() for k, v in coarse.state_dict().items()}
+            pf = {k: v.detach().cpu() for k, v in fine.state_dict().items()}
+            res["cpu_baseline"], psnr = cpu_baseline(syn, pc, pf, tile, r0)
+            res["psnr_vs_cpu_oracle_db"] = psnr
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

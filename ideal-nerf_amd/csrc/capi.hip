@@ -1,0 +1,287 @@
+// extern "C" surface of libidealnerf.so (declared in include/idealnerf.h).
+#include "idn_internal.h"
+#include <cstdarg>
+#include <cstdio>
+
+namespace idn {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int check_precision(int precision) {
+    if (precision == IDN_PREC_F32) return IDN_OK;
+    return fail(IDN_EUNSUPPORTED, "precision %d is not built into this library (only IDN_PREC_F32)", precision);
+}
+
+static int check_params(const idn_facenerf_params* p) {
+    if (!p) return fail(IDN_EINVAL, "params is NULL");
+    for (int i = 0; i < 8; ++i)
+        if (!p->pts_w[i] || !p->pts_b[i]) return fail(IDN_EINVAL, "pts_linears.%d is NULL", i);
+    for (int i = 0; i < 3; ++i)
+        if (!p->views_w[i] || !p->views_b[i]) return fail(IDN_EINVAL, "views_linears.%d is NULL", i);
+    if (!p->alpha_w || !p->alpha_b || !p->rgb_w || !p->rgb_b) return fail(IDN_EINVAL, "alpha/rgb head is NULL");
+    if (p->dim_aud < 0 || p->dim_expr < 0 || p->dim_latent < 0) return fail(IDN_EINVAL, "negative conditioning width");
+    return IDN_OK;
+}
+
+// ---- MLP launch timing (bench.py's roofline figure) ---------------------------------
+// HIP events recorded on the launch stream itself, immediately around the kernel.
+// Process-wide and meant for single-threaded measurement runs only.
+static const int kProfSlots = 8192;
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_ev[kProfSlots][2];
+static int g_prof_created = 0;
+static int64_t g_prof_points[kProfSlots];
+
+ProfScope::ProfScope(hipStream_t s_, int64_t points) : slot(-1), s(s_) {
+    if (!g_prof_on || g_prof_n >= kProfSlots) return;
+    slot = g_prof_n++;
+    if (slot >= g_prof_created) {
+        (void)hipEventCreate(&g_prof_ev[slot][0]);
+        (void)hipEventCreate(&g_prof_ev[slot][1]);
+        g_prof_created = slot + 1;
+    }
+    g_prof_points[slot] = points;
+    (void)hipEventRecord(g_prof_ev[slot][0], s);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof_ev[slot][1], s);
+}
+
+}  // namespace idn
+
+using namespace idn;
+
+extern "C" {
+
+int idealnerf_version(void) { return 1; }
+const char* idealnerf_last_error(void) { return g_err; }
+
+size_t idealnerf_packed_weight_floats(int precision) {
+    return precision == IDN_PREC_F32 ? (size_t)kStreamFrags * kFragFloats : 0;
+}
+size_t idealnerf_folded_bias_floats(void) { return kBiasFloats; }
+
+int idealnerf_pack_weights(const idn_facenerf_params* p, int precision, float* packed, void* stream) {
+    if (int e = check_params(p)) return e;
+    if (int e = check_precision(precision)) return e;
+    if (!packed) return fail(IDN_EINVAL, "packed is NULL");
+    return launch_pack_f32(*p, packed, (hipStream_t)stream);
+}
+
+int idealnerf_fold_conditioning(const idn_facenerf_params* p, const float* aud, const float* expr,
+                                const float* latent, float* folded, void* stream) {
+    if (int e = check_params(p)) return e;
+    if (!folded) return fail(IDN_EINVAL, "folded is NULL");
+    if ((p->dim_aud > 0) != (aud != nullptr)) return fail(IDN_EINVAL, "aud pointer does not match dim_aud=%d", p->dim_aud);
+    if ((p->dim_expr > 0) != (expr != nullptr)) return fail(IDN_EINVAL, "expr pointer does not match dim_expr=%d", p->dim_expr);
+    if ((p->dim_latent > 0) != (latent != nullptr))
+        return fail(IDN_EINVAL, "latent pointer does not match dim_latent=%d", p->dim_latent);
+    return launch_fold(*p, aud, expr, latent, folded, (hipStream_t)stream);
+}
+
+int idealnerf_facenerf_fwd(const float* packed, const float* folded, int precision, const float* x, int64_t n,
+                           float* out, void* stream) {
+    if (int e = check_precision(precision)) return e;
+    if (n < 0) return fail(IDN_EINVAL, "n < 0");
+    if (n == 0) return IDN_OK;
+    if (!packed || !folded || !x || !out) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_mlp_f32(packed, folded, x, nullptr, nullptr, nullptr, nullptr, n, 1, out, (hipStream_t)stream);
+}
+
+int idealnerf_query_rays_fwd(const float* packed, const float* folded, int precision, const float* rays,
+                             const float* z, int64_t n_rays, int n_samples, float* raw, void* stream) {
+    if (int e = check_precision(precision)) return e;
+    if (n_rays < 0 || n_samples < 1) return fail(IDN_EINVAL, "bad sizes n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
+    if (n_rays == 0) return IDN_OK;
+    if (!packed || !folded || !rays || !z || !raw) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_mlp_f32(packed, folded, nullptr, rays, z, nullptr, nullptr, n_rays * n_samples, n_samples, raw,
+                          (hipStream_t)stream);
+}
+
+int idealnerf_query_points_fwd(const float* packed, const float* folded, int precision, const float* pts,
+                               const float* viewdirs, int64_t n_rays, int n_samples, float* raw, void* stream) {
+    if (int e = check_precision(precision)) return e;
+    if (n_rays < 0 || n_samples < 1) return fail(IDN_EINVAL, "bad sizes n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
+    if (n_rays == 0) return IDN_OK;
+    if (!packed || !folded || !pts || !viewdirs || !raw) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_mlp_f32(packed, folded, nullptr, nullptr, nullptr, pts, viewdirs, n_rays * n_samples, n_samples, raw,
+                          (hipStream_t)stream);
+}
+
+int idealnerf_frame_rays(const float* c2w, int H, int W, float focal, float cx, float cy, float near_, float far_,
+                         int row0, int nrows, float* rays_out, void* stream) {
+    if (!c2w || !rays_out) return fail(IDN_EINVAL, "NULL pointer");
+    if (H <= 0 || W <= 0 || row0 < 0 || nrows < 0 || row0 + nrows > H) return fail(IDN_EINVAL, "bad frame/rows");
+    if (nrows == 0) return IDN_OK;
+    return launch_frame_rays(c2w, H, W, focal, cx, cy, near_, far_, row0, nrows, rays_out, (hipStream_t)stream);
+}
+
+int idealnerf_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays,
+                            int n_samples, float* z, void* stream) {
+    if (n_rays < 0 || n_samples < 1) return fail(IDN_EINVAL, "bad sizes");
+    if (n_rays == 0) return IDN_OK;
+    if (!rays || !t_vals || !z) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_coarse_depths(rays, t_vals, t_rand, n_rays, n_samples, z, (hipStream_t)stream);
+}
+
+int idealnerf_composite_fwd(const float* raw, const float* z, const float* rays, const float* bc_rgb,
+                            int64_t n_rays, int n_samples, const idn_composite_out* out, void* stream) {
+    if (n_rays < 0) return fail(IDN_EINVAL, "n_rays < 0");
+    if (n_rays == 0) return IDN_OK;
+    if (!raw || !z || !rays || !bc_rgb || !out) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_composite(raw, z, rays, bc_rgb, n_rays, n_samples, *out, (hipStream_t)stream);
+}
+
+int idealnerf_sample_pdf_fwd(const float* z, const float* weights, const float* u, int u_per_ray, int64_t n_rays,
+                             int n_samples, int n_importance, float* z_samples, int64_t* inds, float* cdf,
+                             float* z_fine, float* z_std, void* stream) {
+    if (n_rays < 0) return fail(IDN_EINVAL, "n_rays < 0");
+    if (n_rays == 0) return IDN_OK;
+    if (!z || !weights || !u) return fail(IDN_EINVAL, "NULL pointer");
+    if (n_samples < 3) return fail(IDN_EUNSUPPORTED, "sample_pdf needs n_samples >= 3");
+    return launch_sample_pdf(z, weights, nullptr, nullptr, u, u_per_ray, n_rays, n_samples, n_importance, z_samples,
+                             inds, cdf, z_fine, z_std, (hipStream_t)stream);
+}
+
+int idealnerf_invert_cdf(const float* cdf, const float* bins, const float* u, int u_per_ray, int64_t n_rays,
+                         int n_bins, int n_importance, float* z_samples, int64_t* inds, void* stream) {
+    if (n_rays < 0) return fail(IDN_EINVAL, "n_rays < 0");
+    if (n_rays == 0) return IDN_OK;
+    if (!cdf || !bins || !u) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_sample_pdf(nullptr, nullptr, cdf, bins, u, u_per_ray, n_rays, n_bins + 1, n_importance, z_samples,
+                             inds, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+void idealnerf_profile_begin(void) {
+    g_prof_n = 0;
+    g_prof_on = true;
+}
+
+int idealnerf_profile_end(double* total_ms, int64_t* launches, int64_t* points) {
+    g_prof_on = false;
+    double ms = 0;
+    int64_t pts = 0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        IDN_HIP_CHECK(hipEventSynchronize(g_prof_ev[i][1]));
+        float t = 0;
+        IDN_HIP_CHECK(hipEventElapsedTime(&t, g_prof_ev[i][0], g_prof_ev[i][1]));
+        ms += t;
+        pts += g_prof_points[i];
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = g_prof_n;
+    if (points) *points = pts;
+    return IDN_OK;
+}
+
+// ---- render_rays --------------------------------------------------------------------
+static const int64_t kRenderChunk = 32768;  // rays per internal pass (bounds the workspace)
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct RenderWs {
+    float *z_c, *raw_c, *w_c, *z_f, *raw_f, *w_f;
+    size_t bytes;
+};
+static RenderWs carve(char* base, int64_t n, int S, int Ni) {
+    RenderWs w;
+    const int64_t c = n < kRenderChunk ? n : kRenderChunk;
+    const int Sf = S + Ni;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* p = reinterpret_cast<float*>(base + off);
+        off += align256(floats * sizeof(float));
+        return p;
+    };
+    w.z_c = take((size_t)c * S);
+    w.raw_c = take((size_t)c * S * 4);
+    w.w_c = take((size_t)c * S);
+    w.z_f = take((size_t)c * Sf);
+    w.raw_f = take((size_t)c * Sf * 4);
+    w.w_f = take((size_t)c * Sf);
+    w.bytes = off;
+    return w;
+}
+
+size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance) {
+    if (n_rays <= 0 || n_samples <= 0 || n_importance < 0) return 0;
+    return carve(nullptr, n_rays, n_samples, n_importance).bytes;
+}
+
+int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
+    if (!a) return fail(IDN_EINVAL, "args is NULL");
+    if (int e = check_precision(a->precision)) return e;
+    const int64_t n = a->n_rays;
+    const int S = a->n_samples, Ni = a->n_importance, Sf = S + Ni;
+    if (n < 0 || S < 2 || Ni < 0) return fail(IDN_EINVAL, "bad sizes n=%lld S=%d Ni=%d", (long long)n, S, Ni);
+    if (n == 0) return IDN_OK;
+    if (!a->rays || !a->bc_rgb || !a->t_vals || !a->packed_coarse || !a->folded_coarse)
+        return fail(IDN_EINVAL, "NULL input pointer");
+    if (Ni > 0 && (!a->packed_fine || !a->folded_fine || !a->u)) return fail(IDN_EINVAL, "fine pass inputs are NULL");
+    if (Ni > 0 && S < 3) return fail(IDN_EUNSUPPORTED, "importance sampling needs n_samples >= 3");
+    const size_t need = idealnerf_render_workspace_bytes(n, S, Ni);
+    if (!a->workspace || a->workspace_bytes < need)
+        return fail(IDN_EWORKSPACE, "workspace %zu bytes < required %zu", a->workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream_;
+    const RenderWs w = carve(reinterpret_cast<char*>(a->workspace), n, S, Ni);
+
+    auto off = [](auto* p, int64_t elems) { return p ? p + elems : p; };
+    auto tap = [&](void* dst, const void* src, size_t bytes) -> int {
+        if (!dst) return IDN_OK;
+        IDN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        return IDN_OK;
+    };
+
+    for (int64_t r0 = 0; r0 < n; r0 += kRenderChunk) {
+        const int64_t c = (n - r0 < kRenderChunk) ? n - r0 : kRenderChunk;
+        const float* rays = a->rays + r0 * IDN_RAY_FLOATS;
+        const float* bc = a->bc_rgb + r0 * 3;
+        if (int e = launch_coarse_depths(rays, a->t_vals, off(a->t_rand, r0 * S), c, S, w.z_c, st)) return e;
+        if (int e = launch_mlp_f32(a->packed_coarse, a->folded_coarse, nullptr, rays, w.z_c, nullptr, nullptr, c * S, S, w.raw_c, st)) return e;
+        idn_composite_out co = {};
+        const bool fine = Ni > 0;
+        co.rgb_map = off(fine ? a->rgb0 : a->rgb_map, r0 * 3);
+        co.disp_map = off(fine ? a->disp0 : a->disp_map, r0);
+        co.acc_map = off(fine ? a->acc0 : a->acc_map, r0);
+        co.depth_map = fine ? nullptr : off(a->depth_map, r0);
+        co.weights = w.w_c;
+        co.rgb_fg = off(fine ? a->rgb_fg0 : a->rgb_fg, r0 * 3);
+        co.last_weight = off(fine ? a->last_weight0 : a->last_weight, r0);
+        if (int e = launch_composite(w.raw_c, w.z_c, rays, bc, c, S, co, st)) return e;
+        if (int e = tap(off(a->tap_z_coarse, r0 * S), w.z_c, (size_t)c * S * 4)) return e;
+        if (int e = tap(off(a->tap_raw_coarse, r0 * S * 4), w.raw_c, (size_t)c * S * 16)) return e;
+        if (int e = tap(off(a->tap_weights_coarse, r0 * S), w.w_c, (size_t)c * S * 4)) return e;
+        if (!fine) continue;
+
+        const float* u = a->u_per_ray ? a->u + r0 * Ni : a->u;
+        if (int e = launch_sample_pdf(w.z_c, w.w_c, nullptr, nullptr, u, a->u_per_ray, c, S, Ni,
+                                      off(a->tap_z_samples, r0 * Ni), off(a->tap_inds, r0 * Ni),
+                                      off(a->tap_cdf, r0 * (S - 1)), w.z_f, off(a->z_std, r0), st))
+            return e;
+        if (int e = launch_mlp_f32(a->packed_fine, a->folded_fine, nullptr, rays, w.z_f, nullptr, nullptr, c * Sf, Sf, w.raw_f, st)) return e;
+        idn_composite_out fo = {};
+        fo.rgb_map = off(a->rgb_map, r0 * 3);
+        fo.disp_map = off(a->disp_map, r0);
+        fo.acc_map = off(a->acc_map, r0);
+        fo.depth_map = off(a->depth_map, r0);
+        fo.weights = a->tap_weights_fine ? w.w_f : nullptr;
+        fo.rgb_fg = off(a->rgb_fg, r0 * 3);
+        fo.last_weight = off(a->last_weight, r0);
+        if (int e = launch_composite(w.raw_f, w.z_f, rays, bc, c, Sf, fo, st)) return e;
+        if (int e = tap(off(a->tap_z_fine, r0 * Sf), w.z_f, (size_t)c * Sf * 4)) return e;
+        if (int e = tap(off(a->tap_raw_fine, r0 * Sf * 4), w.raw_f, (size_t)c * Sf * 16)) return e;
+        if (int e = tap(off(a->tap_weights_fine, r0 * Sf), w.w_f, (size_t)c * Sf * 4)) return e;
+    }
+    return IDN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,406 @@
+// Per-ray stages around the MLP (gfx950): ray generation, coarse depths, alpha
+// compositing, inverse-CDF importance sampling + merge.  One 64-lane wavefront per ray;
+// prefix products / sums are wave-level scans in fp64 (PyTorch-CPU's cumprod / cumsum
+// accumulate in double and round each output to fp32 -- DESIGN.md "numerics").
+//
+// Built with -ffp-contract=off: every product and sum below rounds separately, as the
+// reference's chain of eager ops does; the sample positions feed index decisions.
+#include "idn_internal.h"
+
+namespace idn {
+
+constexpr int kMaxSpl = 4;  // samples per lane: S <= 256
+
+__device__ __forceinline__ double shfl_up_d(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, delta, 64);
+    hi = __shfl_up(hi, delta, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_d(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
+    return v;
+}
+// inclusive scans across the 64 lanes
+__device__ __forceinline__ double wave_scan_mul_d(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = shfl_up_d(v, d);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_scan_add_d(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = shfl_up_d(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// a1: get_rays + record assembly (helper.py:228-243, audio_exp_nerf.py:396-427)
+// ---------------------------------------------------------------------------
+struct C2W {
+    float m[12];
+};
+__global__ void frame_rays_kernel(C2W c, int W, float focal, float cx, float cy, float near_, float far_, int row0,
+                                  int npix, float* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const int row = row0 + idx / W, col = idx % W;
+    const float i = (float)col, j = (float)row;
+    const float d0 = (i - cx) / focal;
+    const float d1 = -(j - cy) / focal;
+    const float d2 = -1.0f;
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = (d0 * c.m[4 * r + 0] + d1 * c.m[4 * r + 1]) + d2 * c.m[4 * r + 2];
+    const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    float* o = out + (long)idx * IDN_RAY_FLOATS;
+    o[0] = c.m[3];
+    o[1] = c.m[7];
+    o[2] = c.m[11];
+    o[3] = d[0];
+    o[4] = d[1];
+    o[5] = d[2];
+    o[6] = near_;
+    o[7] = far_;
+    o[8] = d[0] / nrm;
+    o[9] = d[1] / nrm;
+    o[10] = d[2] / nrm;
+}
+
+int launch_frame_rays(const float* c2w_host, int H, int W, float focal, float cx, float cy, float near_, float far_,
+                      int row0, int nrows, float* rays_out, hipStream_t s) {
+    C2W c;
+    for (int i = 0; i < 12; ++i) c.m[i] = c2w_host[i];
+    if (cx < 0) cx = W * 0.5f;
+    if (cy < 0) cy = H * 0.5f;
+    const int npix = nrows * W;
+    hipLaunchKernelGGL(frame_rays_kernel, dim3((npix + 255) / 256), dim3(256), 0, s, c, W, focal, cx, cy, near_, far_,
+                       row0, npix, rays_out);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a3: coarse depths (audio_exp_nerf.py:306-330)
+// ---------------------------------------------------------------------------
+__global__ void coarse_depths_kernel(const float* rays, const float* t_vals, const float* t_rand, long n_rays, int S,
+                                     float* z) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rays * S) return;
+    const long r = idx / S;
+    const int s = (int)(idx - r * S);
+    const float near_ = rays[r * IDN_RAY_FLOATS + 6], far_ = rays[r * IDN_RAY_FLOATS + 7];
+    auto zlin = [&](int k) {
+        const float t = t_vals[k];
+        return near_ * (1.0f - t) + far_ * t;
+    };
+    float zz = zlin(s);
+    if (t_rand) {
+        const float lower = (s == 0) ? zz : 0.5f * (zz + zlin(s - 1));
+        const float upper = (s == S - 1) ? zz : 0.5f * (zlin(s + 1) + zz);
+        const float tr = (s == S - 1) ? 1.0f : t_rand[idx];
+        zz = lower + (upper - lower) * tr;
+    }
+    z[idx] = zz;
+}
+
+int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays, int S,
+                         float* z, hipStream_t s) {
+    const long total = (long)n_rays * S;
+    if (total <= 0) return IDN_OK;
+    hipLaunchKernelGGL(coarse_depths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rays, t_vals,
+                       t_rand, (long)n_rays, S, z);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a6: raw2outputs (NeRFs/HeadNeRF/train/baseline.py:325-375; rgb_fg: TorsoNeRF/run_nerf.py:757)
+// Lane l owns samples l*SPL .. l*SPL+SPL-1 (contiguous, so a ray's prefix product is a
+// lane-local product followed by one wave scan).
+// ---------------------------------------------------------------------------
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_kernel(const float4* raw, const float* z, const float* rays,
+                                                        const float* bc, long n_rays, int S, idn_composite_out out) {
+    const int lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;  // wave-uniform
+    const float* rr = rays + ray * IDN_RAY_FLOATS;
+    const float dn = sqrtf((rr[3] * rr[3] + rr[4] * rr[4]) + rr[5] * rr[5]);  // torch.norm(rays_d)
+    const float4* rawr = raw + ray * S;
+    const float* zr = z + ray * S;
+
+    float zs[SPL + 1];
+    float4 rw[SPL];
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        const bool ok = s < S;
+        zs[i] = ok ? zr[s] : 0.f;
+        rw[i] = ok ? rawr[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    zs[SPL] = __shfl_down(zs[0], 1, 64);  // first sample of the next lane
+
+    float alpha[SPL], tf[SPL];
+    double local = 1.0;  // product of this lane's (1 - alpha + 1e-10)
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        float dist = (s >= S - 1) ? 1e10f : (zs[i + 1] - zs[i]);
+        dist = dist * dn;
+        const float a = 1.0f - expf(-(fmaxf(rw[i].w, 0.0f) + 1e-6f) * dist);
+        alpha[i] = (s < S) ? a : 0.0f;
+        tf[i] = (s < S) ? (1.0f - a) + 1e-10f : 1.0f;
+        local *= (double)tf[i];
+    }
+    const double incl = wave_scan_mul_d(local, lane);
+    double run = shfl_up_d(incl, 1);  // exclusive prefix over lanes
+    if (lane == 0) run = 1.0;
+
+    double sr = 0, sg = 0, sb = 0, sd = 0, sw = 0, fr = 0, fg = 0, fb = 0;
+    float wlast = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        const float T = (float)run;  // cumprod output, rounded to fp32 per element
+        const float w = alpha[i] * T;
+        run *= (double)tf[i];
+        if (s < S) {
+            float cr, cg, cb;
+            if (s == S - 1) {  // last sample's colour := background pixel (baseline.py:352)
+                cr = bc[ray * 3 + 0];
+                cg = bc[ray * 3 + 1];
+                cb = bc[ray * 3 + 2];
+                wlast = w;
+            } else {
+                cr = 1.0f / (1.0f + expf(-rw[i].x));
+                cg = 1.0f / (1.0f + expf(-rw[i].y));
+                cb = 1.0f / (1.0f + expf(-rw[i].z));
+                fr += (double)(w * cr);
+                fg += (double)(w * cg);
+                fb += (double)(w * cb);
+            }
+            sr += (double)(w * cr);
+            sg += (double)(w * cg);
+            sb += (double)(w * cb);
+            sd += (double)(w * zs[i]);
+            sw += (double)w;
+            if (out.weights) out.weights[ray * S + s] = w;
+        }
+    }
+    sr = wave_sum_d(sr); sg = wave_sum_d(sg); sb = wave_sum_d(sb);
+    sd = wave_sum_d(sd); sw = wave_sum_d(sw);
+    if (out.rgb_fg) { fr = wave_sum_d(fr); fg = wave_sum_d(fg); fb = wave_sum_d(fb); }
+    if (out.last_weight) {
+        // the lane owning sample S-1 holds it
+        const int owner = (S - 1) / SPL;
+        const float lw = __shfl(wlast, owner, 64);
+        if (lane == 0) out.last_weight[ray] = lw;
+    }
+    if (lane == 0) {
+        const float depth = (float)sd, acc = (float)sw;
+        if (out.rgb_map) {
+            out.rgb_map[ray * 3 + 0] = (float)sr;
+            out.rgb_map[ray * 3 + 1] = (float)sg;
+            out.rgb_map[ray * 3 + 2] = (float)sb;
+        }
+        if (out.rgb_fg) {
+            out.rgb_fg[ray * 3 + 0] = (float)fr;
+            out.rgb_fg[ray * 3 + 1] = (float)fg;
+            out.rgb_fg[ray * 3 + 2] = (float)fb;
+        }
+        if (out.depth_map) out.depth_map[ray] = depth;
+        if (out.acc_map) out.acc_map[ray] = acc;
+        if (out.disp_map) out.disp_map[ray] = 1.0f / fmaxf(1e-10f, depth / acc);
+    }
+}
+
+int launch_composite(const float* raw, const float* z, const float* rays, const float* bc, int64_t n_rays, int S,
+                     const idn_composite_out& out, hipStream_t s) {
+    if (n_rays <= 0) return IDN_OK;
+    if (S < 2 || S > 64 * kMaxSpl) return fail(IDN_EUNSUPPORTED, "composite: n_samples %d outside [2, %d]", S, 64 * kMaxSpl);
+    const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
+    const float4* r4 = reinterpret_cast<const float4*>(raw);
+    const int spl = (S + 63) / 64;
+    switch (spl) {
+        case 1: hipLaunchKernelGGL(composite_kernel<1>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, out); break;
+        case 2: hipLaunchKernelGGL(composite_kernel<2>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, out); break;
+        case 3: hipLaunchKernelGGL(composite_kernel<3>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, out); break;
+        default: hipLaunchKernelGGL(composite_kernel<4>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, out); break;
+    }
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a7 + a8: sample_pdf (helper.py:269-313) and sorted merge (audio_exp_nerf.py:347-349)
+//
+// Per ray (one wave): bins / cdf staged in LDS, inverse CDF by binary search
+// (searchsorted right=True: inds = #{k : cdf[k] <= u}), merge by rank counting (values
+// only are kept, so any stable total order gives torch.sort's values).
+// ---------------------------------------------------------------------------
+constexpr int kMaxBins = 256;   // S - 1 <= 255
+constexpr int kMaxNi = 256;
+constexpr int kMaxFine = 512;
+
+struct SampleArgs {
+    const float* z;        // [n,S] coarse depths (null when cdf_in/bins_in are given)
+    const float* weights;  // [n,S]
+    const float* cdf_in;   // [n,nb] optional: skip the pdf/cdf stage (bit-exact boundary)
+    const float* bins_in;  // [n,nb]
+    const float* u;
+    int u_per_ray;
+    long n_rays;
+    int S, Ni, nb;
+    float* z_samples;
+    int64_t* inds;
+    float* cdf_out;
+    float* z_fine;
+    float* z_std;
+};
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(SampleArgs a) {
+    __shared__ float s_cdf[4][kMaxBins];
+    __shared__ float s_bins[4][kMaxBins];
+    __shared__ float s_val[4][kMaxFine];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long ray = (long)blockIdx.x * 4 + wv;
+    if (ray >= a.n_rays) return;  // wave-uniform; no block-level barrier below
+    float* cdf = s_cdf[wv];
+    float* bins = s_bins[wv];
+    float* val = s_val[wv];
+    const int nb = a.nb;
+
+    if (a.cdf_in) {
+        for (int k = lane; k < nb; k += 64) {
+            cdf[k] = a.cdf_in[ray * nb + k];
+            bins[k] = a.bins_in[ray * nb + k];
+        }
+    } else {
+        const float* zr = a.z + ray * a.S;
+        const float* wr = a.weights + ray * a.S;
+        // bins = z midpoints; w' = w[1:-1] + 1e-5; lane l owns pdf entries l*4 .. l*4+3
+        for (int k = lane; k < nb; k += 64) bins[k] = 0.5f * (zr[k + 1] + zr[k]);
+        const int np = a.S - 2;
+        float wp[4];
+        double loc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane * 4 + i;
+            wp[i] = (k < np) ? wr[k + 1] + 1e-5f : 0.0f;
+            loc += (double)wp[i];
+        }
+        const float total = (float)wave_sum_d(loc);  // torch.sum(weights, -1)
+        double pl = 0.0;
+        float pdf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pdf[i] = wp[i] / total;
+            pl += (double)pdf[i];
+        }
+        const double incl = wave_scan_add_d(pl, lane);
+        double run = incl - pl;  // exclusive prefix (sum of earlier lanes)
+        if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane * 4 + i;
+            run += (double)pdf[i];
+            if (k < np) cdf[k + 1] = (float)run;  // cumsum output rounded per element
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes of this wave are done
+    if (a.cdf_out)
+        for (int k = lane; k < nb; k += 64) a.cdf_out[ray * nb + k] = cdf[k];
+
+    // ---- inverse CDF
+    double m1 = 0.0;
+    float zsv[kMaxNi / 64];
+#pragma unroll
+    for (int ii = 0; ii < kMaxNi / 64; ++ii) {
+        const int i = ii * 64 + lane;
+        zsv[ii] = 0.f;
+        if (i < a.Ni) {
+            const float u = a.u_per_ray ? a.u[ray * a.Ni + i] : a.u[i];
+            int lo = 0, hi = nb;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] <= u) lo = mid + 1;
+                else hi = mid;
+            }
+            const int below = max(0, lo - 1), above = min(nb - 1, lo);
+            const float cb = cdf[below], ca = cdf[above];
+            const float bb = bins[below], ba = bins[above];
+            float denom = ca - cb;
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (u - cb) / denom;
+            const float zsamp = bb + t * (ba - bb);
+            zsv[ii] = zsamp;
+            m1 += (double)zsamp;
+            if (a.inds) a.inds[ray * a.Ni + i] = (int64_t)lo;
+            if (a.z_samples) a.z_samples[ray * a.Ni + i] = zsamp;
+        }
+    }
+    if (a.z_std) {  // torch.std(z_samples, unbiased=False)  (audio_exp_nerf.py:363)
+        const double mean = wave_sum_d(m1) / (double)a.Ni;
+        double m2 = 0.0;
+#pragma unroll
+        for (int ii = 0; ii < kMaxNi / 64; ++ii)
+            if (ii * 64 + lane < a.Ni) {
+                const double dlt = (double)zsv[ii] - mean;
+                m2 += dlt * dlt;
+            }
+        m2 = wave_sum_d(m2);
+        if (lane == 0) a.z_std[ray] = (float)sqrt(m2 / (double)a.Ni);
+    }
+    // ---- z_fine = sort(cat[z_coarse, z_samples])
+    if (a.z_fine) {
+        const int nf = a.S + a.Ni;
+        const float* zr = a.z + ray * a.S;
+        for (int k = lane; k < a.S; k += 64) val[k] = zr[k];
+#pragma unroll
+        for (int ii = 0; ii < kMaxNi / 64; ++ii)
+            if (ii * 64 + lane < a.Ni) val[a.S + ii * 64 + lane] = zsv[ii];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        for (int e = lane; e < nf; e += 64) {
+            const float v = val[e];
+            int rank = 0;
+            for (int j = 0; j < nf; ++j) {
+                const float o = val[j];
+                rank += (o < v || (o == v && j < e)) ? 1 : 0;
+            }
+            a.z_fine[ray * nf + rank] = v;
+        }
+    }
+}
+
+int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in, const float* bins_in,
+                      const float* u, int u_per_ray, int64_t n_rays, int S, int Ni, float* z_samples,
+                      int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s) {
+    if (n_rays <= 0) return IDN_OK;
+    const int nb = S - 1;
+    if (nb < 2 || nb > kMaxBins - 1) return fail(IDN_EUNSUPPORTED, "sample_pdf: %d bins outside [2, %d]", nb, kMaxBins - 1);
+    if (Ni < 1 || Ni > kMaxNi) return fail(IDN_EUNSUPPORTED, "sample_pdf: n_importance %d outside [1, %d]", Ni, kMaxNi);
+    if (S + Ni > kMaxFine) return fail(IDN_EUNSUPPORTED, "sample_pdf: n_samples + n_importance > %d", kMaxFine);
+    SampleArgs a{z, weights, cdf_in, bins_in, u, u_per_ray, (long)n_rays, S, Ni, nb, z_samples, inds, cdf_out, z_fine, z_std};
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, s, a);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+}  // namespace idn

@@ -1,0 +1,106 @@
+// Internal declarations shared by the HIP translation units of libidealnerf.so.
+// gfx950 only.  See DESIGN.md for the data layout this header encodes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/idealnerf.h"
+
+namespace idn {
+
+// ---------------------------------------------------------------------------
+// Packed weight stream (fp32 path).
+//
+// The per-point part of one FaceNeRF is a flat sequence of 1 KiB "fragments" in the
+// exact order the kernel consumes them.  Fragment (layer, g, t) holds, for lane
+// l = (i = l & 31, h = l >> 5), the four floats
+//      W_layer[n = 32 t + i][k = 8 g + 4 h + j],  j = 0..3
+// i.e. the A operands of four consecutive v_mfma_f32_32x32x2_f32 whose B operands
+// are registers 4q..4q+3 (q = g & 3) of accumulator tile T = g >> 2 of the previous
+// layer: an accumulator register r of tile T holds, in lane half h, output channel
+// 32 T + (r & 3) + 8 (r >> 2) + 4 h = 8 g + 4 h + j.  Activations therefore never
+// leave registers between layers.
+//
+// Within a layer, fragments are ordered g-major then t.  K sources are concatenated in
+// k-groups of 8 channels (zero padded): PE(63 -> 8 groups), hidden (256 -> 32 groups),
+// direction PE (27 -> 4 groups).  The conditioning columns are not in the stream; they
+// are folded into the per-frame bias block (idealnerf_fold_conditioning).
+// ---------------------------------------------------------------------------
+constexpr int kFragBytes = 1024;
+constexpr int kFragFloats = 256;
+constexpr int kSliceFrags = 64;                 // one LDS ring slot = 64 KiB
+constexpr int kRingFrags = 2 * kSliceFrags;     // 128 KiB ring
+constexpr int kSliceBytes = kSliceFrags * kFragBytes;
+
+constexpr int kNumLayers = 12;  // pts0..7, views0(+alpha), views1, views2, rgb
+// n-tiles (of 32 output channels) and k-groups (of 8 input channels) per layer
+constexpr int kLayerNT[kNumLayers] = {8, 8, 8, 8, 8, 8, 8, 8, 5, 4, 4, 1};
+constexpr int kLayerKG[kNumLayers] = {8, 32, 32, 32, 32, 40, 32, 32, 36, 16, 16, 16};
+
+constexpr int layer_f0(int l) {
+    int f = 0;
+    for (int i = 0; i < l; ++i) f += kLayerNT[i] * kLayerKG[i];
+    return f;
+}
+constexpr int kUsedFrags = layer_f0(kNumLayers);                                  // 2244
+constexpr int kNumSlices = ((kUsedFrags + kSliceFrags - 1) / kSliceFrags + 1) / 2 * 2;  // even: 36
+constexpr int kStreamFrags = kNumSlices * kSliceFrags;                            // 2304
+static_assert(kUsedFrags == 2244, "layer table changed");
+static_assert(kNumSlices % 2 == 0, "ring parity must be static across passes");
+
+// Folded bias block: one float per output channel, natural channel order
+// (accumulator register 4q+j of tile t, lane half h <-> channel 32 t + 8 q + 4 h + j).
+constexpr int bias_off(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += kLayerNT[i] * 32;
+    return o;
+}
+constexpr int kBiasFloats = bias_off(kNumLayers);  // 2496
+static_assert(kBiasFloats == 2496, "bias table changed");
+
+// views0 carries sigma as channel 128 (tile 4, row 0): alpha_linear rides in the same
+// pass over the trunk output instead of a separate N=1 layer.
+constexpr int kSigmaChannel = 128;
+
+// ---------------------------------------------------------------------------
+// error plumbing (capi.hip)
+// ---------------------------------------------------------------------------
+int fail(int code, const char* fmt, ...);
+#define IDN_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return ::idn::fail(IDN_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// optional per-launch timing of the MLP kernel (capi.hip); off by default
+// ---------------------------------------------------------------------------
+struct ProfScope {
+    int slot;
+    hipStream_t s;
+    ProfScope(hipStream_t s, int64_t points);
+    ~ProfScope();
+};
+
+// ---------------------------------------------------------------------------
+// launchers (one per .hip file)
+// ---------------------------------------------------------------------------
+int launch_pack_f32(const idn_facenerf_params& p, float* packed, hipStream_t s);
+int launch_fold(const idn_facenerf_params& p, const float* aud, const float* expr, const float* latent,
+                float* folded, hipStream_t s);
+// x != nullptr: pre-embedded rows [n_points, 90]; pts != nullptr: raw points [n_points,3] +
+// dirs[n_points/S, 3]; else rays[n_rays,11] + z[n_rays,S]
+int launch_mlp_f32(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
+                   const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
+
+int launch_frame_rays(const float* c2w, int H, int W, float focal, float cx, float cy, float near_, float far_,
+                      int row0, int nrows, float* rays_out, hipStream_t s);
+int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays, int S,
+                         float* z, hipStream_t s);
+int launch_composite(const float* raw, const float* z, const float* rays, const float* bc, int64_t n_rays, int S,
+                     const idn_composite_out& out, hipStream_t s);
+int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in, const float* bins_in,
+                      const float* u, int u_per_ray, int64_t n_rays, int S, int Ni, float* z_samples,
+                      int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s);
+
+}  // namespace idn

@@ -1,0 +1,150 @@
+// Load-time and per-frame preparation kernels (gfx950):
+//   pack:  state_dict tensors -> MFMA-fragment weight stream (layout: idn_internal.h)
+//   fold:  per-frame conditioning vectors -> bias block
+// Together they are the part of FaceNeRF.forward (models/face_nerf.py:41-55,58,61,68-70)
+// that is constant per frame: the broadcast [aud | expr/3 | latent] columns of layers 0 and 5
+// and the expr/3 columns of views_linears.0 contribute W[:, cols] . vector, a bias.
+#include "idn_internal.h"
+
+namespace idn {
+
+struct PackLayer {
+    const float* w;        // [rows, ld] nn.Linear weight
+    const float* w_extra;  // optional single row appended as channel `rows_extra_at` (alpha_linear)
+    int ld;
+    int rows;              // valid output channels taken from w
+    int extra_at;          // channel index of the extra row
+    int f0, nt, kg, kg0;   // stream position; k-groups [0,kg0) read source 0, the rest source 1
+    int col0[2];           // first column of each source inside w
+    int kvalid[2];         // channels present in each source (rest of the k-group is zero)
+};
+struct PackDesc {
+    PackLayer L[kNumLayers];
+};
+
+__global__ void pack_f32_kernel(PackDesc d, float4* out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= kStreamFrags * 64) return;
+    const int f = gid >> 6, lane = gid & 63;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (f < kUsedFrags) {
+        int l = 0;
+        while (l + 1 < kNumLayers && f >= d.L[l + 1].f0) ++l;
+        const PackLayer& L = d.L[l];
+        const int rel = f - L.f0;
+        const int g = rel / L.nt, t = rel - g * L.nt;
+        const int n = 32 * t + (lane & 31);
+        const int src = g < L.kg0 ? 0 : 1;
+        const int kbase = 8 * (src ? g - L.kg0 : g) + 4 * (lane >> 5);
+        for (int j = 0; j < 4; ++j) {
+            const int k = kbase + j;
+            if (k < L.kvalid[src]) {
+                if (n < L.rows) v[j] = L.w[(long)n * L.ld + L.col0[src] + k];
+                else if (L.w_extra && n == L.extra_at && src == 0) v[j] = L.w_extra[k];
+            }
+        }
+    }
+    out[gid] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+int launch_pack_f32(const idn_facenerf_params& p, float* packed, hipStream_t s) {
+    const int C = p.dim_aud + p.dim_expr + p.dim_latent;
+    PackDesc d;
+    for (int l = 0; l < kNumLayers; ++l) {
+        PackLayer& L = d.L[l];
+        L.w_extra = nullptr;
+        L.extra_at = -1;
+        L.f0 = layer_f0(l);
+        L.nt = kLayerNT[l];
+        L.kg = kLayerKG[l];
+        L.kg0 = L.kg;
+        L.col0[0] = L.col0[1] = 0;
+        L.kvalid[0] = L.kvalid[1] = 0;
+        if (l == 0) {  // [PE(63) | cond(C)] -> 256 ; cond folded
+            L.w = p.pts_w[0]; L.ld = IDN_PTS_CH + C; L.rows = IDN_W; L.kvalid[0] = IDN_PTS_CH;
+        } else if (l == 5) {  // [PE(63) | cond(C) | h(256)] -> 256
+            L.w = p.pts_w[5]; L.ld = IDN_PTS_CH + C + IDN_W; L.rows = IDN_W; L.kg0 = 8;
+            L.kvalid[0] = IDN_PTS_CH; L.col0[1] = IDN_PTS_CH + C; L.kvalid[1] = IDN_W;
+        } else if (l < 8) {
+            L.w = p.pts_w[l]; L.ld = IDN_W; L.rows = IDN_W; L.kvalid[0] = IDN_W;
+        } else if (l == 8) {  // [h(256) | dirPE(27) | expr] -> 128, plus alpha_linear as channel 128
+            L.w = p.views_w[0]; L.ld = IDN_W + IDN_VIEWS_CH + p.dim_expr; L.rows = IDN_W / 2; L.kg0 = 32;
+            L.kvalid[0] = IDN_W; L.col0[1] = IDN_W; L.kvalid[1] = IDN_VIEWS_CH;
+            L.w_extra = p.alpha_w; L.extra_at = kSigmaChannel;
+        } else if (l < 11) {
+            L.w = p.views_w[l - 8]; L.ld = IDN_W / 2; L.rows = IDN_W / 2; L.kvalid[0] = IDN_W / 2;
+        } else {
+            L.w = p.rgb_w; L.ld = IDN_W / 2; L.rows = 3; L.kvalid[0] = IDN_W / 2;
+        }
+    }
+    const int total = kStreamFrags * 64;
+    hipLaunchKernelGGL(pack_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d,
+                       reinterpret_cast<float4*>(packed));
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+struct FoldDesc {
+    idn_facenerf_params p;
+    const float* aud;
+    const float* expr;
+    const float* latent;
+};
+
+// cond[c] of the reference's `initial[:, 63:]` (face_nerf.py:45-55): aud | expr*1/3 | latent
+__device__ __forceinline__ float cond_at(const FoldDesc& d, int c) {
+    if (c < d.p.dim_aud) return d.aud[c];
+    c -= d.p.dim_aud;
+    if (c < d.p.dim_expr) return d.expr[c] * 1.0f / 3.0f;
+    c -= d.p.dim_expr;
+    return d.latent[c];
+}
+
+__global__ void fold_kernel(FoldDesc d, float* out) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= kBiasFloats) return;
+    int l = o / 256, n = o % 256;
+    if (o >= bias_off(8)) {
+        const int r = o - bias_off(8);
+        if (r < 160) { l = 8; n = r; }
+        else if (r < 160 + 128) { l = 9; n = r - 160; }
+        else if (r < 160 + 256) { l = 10; n = r - 288; }
+        else { l = 11; n = r - 416; }
+    }
+    const int C = d.p.dim_aud + d.p.dim_expr + d.p.dim_latent;
+    float b = 0.f;
+    if (l < 8) {
+        b = d.p.pts_b[l][n];
+        if (l == 0 || l == 5) {
+            const int ld = IDN_PTS_CH + C + (l == 5 ? IDN_W : 0);
+            const float* row = d.p.pts_w[l] + (long)n * ld + IDN_PTS_CH;
+            for (int c = 0; c < C; ++c) b = fmaf(row[c], cond_at(d, c), b);
+        }
+    } else if (l == 8) {
+        if (n < IDN_W / 2) {
+            b = d.p.views_b[0][n];
+            if (d.expr) {
+                const int ld = IDN_W + IDN_VIEWS_CH + d.p.dim_expr;
+                const float* row = d.p.views_w[0] + (long)n * ld + IDN_W + IDN_VIEWS_CH;
+                for (int e = 0; e < d.p.dim_expr; ++e) b = fmaf(row[e], d.expr[e] * 1.0f / 3.0f, b);
+            }
+        } else if (n == kSigmaChannel) {
+            b = d.p.alpha_b[0];
+        }
+    } else if (l < 11) {
+        b = d.p.views_b[l - 8][n];
+    } else if (n < 3) {
+        b = d.p.rgb_b[n];
+    }
+    out[o] = b;
+}
+
+int launch_fold(const idn_facenerf_params& p, const float* aud, const float* expr, const float* latent,
+                float* folded, hipStream_t s) {
+    FoldDesc d{p, aud, expr, latent};
+    hipLaunchKernelGGL(fold_kernel, dim3((kBiasFloats + 255) / 256), dim3(256), 0, s, d, folded);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+}  // namespace idn

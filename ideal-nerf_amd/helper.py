@@ -1,0 +1,123 @@
+"""Render-math helpers with the reference's names and signatures
+(NeRFs/HeadNeRF/helper.py:148-313, NeRFs/HeadNeRF/train/baseline.py:325-375), computed by
+libidealnerf.so.  Flags live in an explicit ``RenderConfig`` instead of the reference's
+import-time ``args`` global (helper.py:141-142).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+@dataclass
+class RenderConfig:
+    """The subset of the reference's flags the per-ray path reads (helper.py:16-138)."""
+    netdepth: int = 8
+    netwidth: int = 256
+    dim_aud: int = 64
+    dim_expr: int = 76
+    dim_latent: int = 32
+    win_size: int = 16
+    smo_size: int = 8
+    nosmo_iters: int = 300000
+    N_samples: int = 64
+    N_importance: int = 128
+    perturb: float = 1.0          # reference default (helper.py:70); eval runs pass 0
+    chunk: int = 1024 * 8
+    netchunk: int = 1024 * 64
+    multires: int = 10
+    multires_views: int = 4
+    use_viewdirs: bool = True
+    near: float = 0.3
+    far: float = 0.9
+    lc_weight: float = 0.0005
+
+
+def img2mse(x, y):
+    return torch.nn.functional.mse_loss(x, y)
+
+
+def mse2psnr(x):
+    return -10.0 * torch.log(x) / torch.log(torch.tensor([10.0], device=x.device))
+
+
+def to8b(x):
+    return (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+_linspace_cache = {}
+
+
+def linspace01(n: int, device) -> torch.Tensor:
+    """torch.linspace(0, 1, n) evaluated on the CPU exactly as the reference does
+    (audio_exp_nerf.py:306, helper.py:280) and cached on the device: its roundings are not
+    re-derivable in a kernel and they feed index decisions (DESIGN.md "numerics")."""
+    key = (n, str(device))
+    t = _linspace_cache.get(key)
+    if t is None:
+        t = torch.linspace(0.0, 1.0, steps=n).to(device)
+        _linspace_cache[key] = t
+    return t
+
+
+def get_embedder(multires, i=0, input_dims=3):
+    """helper.py:207-224.  The per-point encodings are fused into the MLP kernel; this
+    standalone embedder only serves per-frame vectors (torso pose signal,
+    train_torso.py:238-240) and is plain tensor math on whatever device x lives on."""
+    if i == -1:
+        return torch.nn.Identity(), input_dims
+    out_dim = input_dims * (1 + 2 * multires)
+
+    def embed(x):
+        feats = [x]
+        for b in range(multires):
+            f = float(2 ** b)
+            feats += [torch.sin(x * f), torch.cos(x * f)]
+        return torch.cat(feats, -1)
+
+    return embed, out_dim
+
+
+def get_rays(H, W, focal, c2w, cx=None, cy=None, near=0.0, far=1.0, row0=0, nrows=None, device="cuda"):
+    """helper.py:228-243 on the GPU.  Returns (rays_o, rays_d) [nrows, W, 3]."""
+    rec = ops.frame_rays(c2w.detach().cpu(), H, W, focal, near, far, row0, nrows, cx, cy, device)
+    nrows = H - row0 if nrows is None else nrows
+    return rec[:, 0:3].reshape(nrows, W, 3), rec[:, 3:6].reshape(nrows, W, 3)
+
+
+def _as_records(rays_d, z_like):
+    """raw2outputs only needs |d|: build ray records with d filled in."""
+    n = rays_d.shape[0]
+    rec = torch.zeros((n, 11), dtype=torch.float32, device=rays_d.device)
+    rec[:, 3:6] = rays_d
+    return rec
+
+
+def raw2outputs(raw, z_vals, rays_d, bc_rgb, raw_noise_std=0.0, white_bkgd=False, pytest=False):
+    """baseline.py:325-375 -> (rgb_map, disp_map, acc_map, weights, depth_map)."""
+    if raw_noise_std > 0.0 or white_bkgd:
+        raise NotImplementedError("raw_noise_std / white_bkgd are never enabled by the reference's Network "
+                                  "(audio_exp_nerf.py:297-299) and are not compiled")
+    o = ops.composite_fwd(raw.contiguous(), z_vals.contiguous(), _as_records(rays_d, z_vals), bc_rgb.contiguous())
+    return o["rgb_map"], o["disp_map"], o["acc_map"], o["weights"], o["depth_map"]
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
+    """helper.py:269-313: bins [n, nb], weights [n, nb-1] -> samples [n, N_samples]."""
+    dev = bins.device
+    n, nb = bins.shape
+    if u is None:
+        if det:
+            u = linspace01(N_samples, dev)
+        elif pytest:
+            np.random.seed(0)
+            u = torch.Tensor(np.random.rand(n, N_samples)).to(dev)
+        else:
+            u = torch.rand((n, N_samples), device=dev)
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    zs, _ = ops.invert_cdf(cdf.contiguous(), bins.contiguous(), u.contiguous())
+    return zs

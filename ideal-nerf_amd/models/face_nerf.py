@@ -1,0 +1,79 @@
+"""Drop-in for the reference's ``models.face_nerf.FaceNeRF`` (models/face_nerf.py:8-80).
+
+Same constructor, same ``forward(x, aud, expr=None, latent_code=None) -> [N, 4]``, same
+``state_dict`` keys (including the never-applied ``feature_linear``), so checkpoints
+load unchanged.  The arithmetic runs in libidealnerf.so: the parameters are re-laid into
+the MFMA weight stream once per update, the per-frame conditioning vectors are folded
+into biases once per call, and the per-point contraction is one fused HIP kernel.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class FaceNeRF(nn.Module):
+    def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, dim_aud=64, dim_latent=0, dim_expr=0,
+                 output_ch=4, skips=None, use_viewdirs=True):
+        super().__init__()
+        if skips is None:
+            skips = [4]
+        self.D, self.W = D, W
+        self.input_xyz_ch, self.input_views_ch = input_ch, input_ch_views
+        self.dim_aud, self.dim_expr, self.dim_latent = dim_aud, dim_expr, dim_latent
+        self.skips, self.use_viewdirs = skips, use_viewdirs
+        if (D, W, list(skips), input_ch, input_ch_views, bool(use_viewdirs)) != (8, 256, [4], 63, 27, True):
+            raise NotImplementedError(
+                "libidealnerf is compiled for the reference's fixed architecture D=8, W=256, skips=[4], "
+                "input_ch=63, input_ch_views=27, use_viewdirs=True (audio_exp_nerf.py:213-224)")
+        c_all = input_ch + dim_aud + dim_expr + dim_latent
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(c_all, W)] + [nn.Linear(W, W) if i not in skips else nn.Linear(W + c_all, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList(
+            [nn.Linear(input_ch_views + W + dim_expr, W // 2)] + [nn.Linear(W // 2, W // 2) for _ in range(D // 4)])
+        self.feature_linear = nn.Linear(W, W)  # present for checkpoint compatibility; never applied upstream
+        self.alpha_linear = nn.Linear(W, 1)
+        self.rgb_linear = nn.Linear(W // 2, 3)
+        self._packed = None
+        self._packed_key = None
+
+    # -- kernel-side views of the parameters ------------------------------------------
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def kernel_params(self):
+        sd = {k: v for k, v in self.named_parameters()}
+        return ops.params_struct(sd, self.dim_aud, self.dim_expr, self.dim_latent)
+
+    def packed_weights(self) -> torch.Tensor:
+        """MFMA-fragment weight stream, rebuilt only when a parameter changed."""
+        key = self._param_key()
+        if self._packed is None or self._packed_key != key:
+            dev = self.alpha_linear.weight.device
+            with torch.no_grad():
+                self._packed = ops.pack_weights(self.kernel_params(), dev)
+            self._packed_key = key
+        return self._packed
+
+    def folded_bias(self, aud, expr=None, latent_code=None) -> torch.Tensor:
+        self._check_cond(aud, expr, latent_code)
+        dev = self.alpha_linear.weight.device
+        f = lambda t: None if t is None else t.detach().to(dtype=torch.float32).contiguous()
+        return ops.fold_conditioning(self.kernel_params(), f(aud), f(expr), f(latent_code), dev)
+
+    def _check_cond(self, aud, expr, latent_code):
+        for name, t, d in (("aud", aud, self.dim_aud), ("expr", expr, self.dim_expr),
+                           ("latent_code", latent_code, self.dim_latent)):
+            have = 0 if t is None else t.numel()
+            if have != d:
+                # the reference fails inside addmm with a shape RuntimeError
+                raise RuntimeError(f"FaceNeRF: {name} has {have} elements, the network was built for {d}")
+
+    def forward(self, x, aud, expr=None, latent_code=None):
+        self._check_cond(aud, expr, latent_code)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ..autograd import facenerf_apply
+            return facenerf_apply(self, x, aud, expr, latent_code)
+        with torch.no_grad():
+            folded = self.folded_bias(aud, expr, latent_code)
+            return ops.facenerf_fwd(self.packed_weights(), folded, x.detach().to(torch.float32).contiguous())

@@ -1,0 +1,224 @@
+/*
+ * idealnerf.h -- C ABI of libidealnerf.so, the MI355X (gfx950) implementation of
+ * IDEAL-NeRF's per-ray hot path.
+ *
+ * The reference (GaryGky/IDEAL-NeRF) is pure Python and has no FFI of its own; its
+ * seam for this path is the set of Python callables listed beside each entry point
+ * below (paths relative to the reference root).  The Python host layer in
+ * ideal-nerf_amd/ mirrors those callables and binds this header through ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major memory owned by the
+ *     caller (fp32 unless stated; indices int64), except where marked [host];
+ *   - `stream` is a hipStream_t passed as void*; calls enqueue work and return, they
+ *     never synchronise, allocate or free;
+ *   - return 0 on success, a negative IDN_E* code otherwise; idealnerf_last_error()
+ *     returns a thread-local message for the last failure on the calling thread;
+ *   - no global mutable state: calls on different streams/devices are independent
+ *     (the reference's nn.DataParallel replicas call forward concurrently,
+ *     NeRFs/HeadNeRF/test/eval_aud_exp_nerf.py:475).
+ *
+ * Network architecture is the reference's fixed one: D=8, W=256, skips=[4],
+ * multires=10 (63 ch), multires_views=4 (27 ch), use_viewdirs=True
+ * (NeRFs/HeadNeRF/train/audio_exp_nerf.py:213-224).  The conditioning widths
+ * (dim_aud, dim_expr, dim_latent) are free: they only enter the per-frame folded
+ * biases.  Other architectures are rejected with IDN_EUNSUPPORTED.
+ */
+#ifndef IDEALNERF_H
+#define IDEALNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDN_OK 0
+#define IDN_EINVAL (-1)       /* bad argument (null pointer, bad size) */
+#define IDN_EUNSUPPORTED (-2) /* architecture / size outside the compiled path */
+#define IDN_EHIP (-3)         /* a HIP runtime call failed (message has the code) */
+#define IDN_EWORKSPACE (-4)   /* workspace too small */
+
+/* Fixed architecture constants (models/face_nerf.py:9-37 at the reference's flags). */
+#define IDN_W 256
+#define IDN_D 8
+#define IDN_PTS_CH 63
+#define IDN_VIEWS_CH 27
+#define IDN_RAY_FLOATS 11 /* o(3) d(3) near far viewdir(3): audio_exp_nerf.py:412-427 */
+
+/* Arithmetic of the MLP contraction. */
+#define IDN_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains */
+#define IDN_PREC_BF16X3 1 /* 3 bf16 MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulate */
+#define IDN_PREC_BF16 2   /* plain bf16 MFMA, fp32 accumulate (BASELINE config 5 only) */
+
+int idealnerf_version(void);
+const char* idealnerf_last_error(void);
+
+/* Sizes (in floats) of the two per-network device buffers the kernels consume. */
+size_t idealnerf_packed_weight_floats(int precision);
+size_t idealnerf_folded_bias_floats(void);
+
+/*
+ * The 24 parameter tensors of one FaceNeRF in state_dict order, nn.Linear layout
+ * [out, in] (models/face_nerf.py:27-37):
+ *   pts_w[i]/pts_b[i], i=0..7      pts_linears.i.{weight,bias}
+ *   views_w[i]/views_b[i], i=0..2  views_linears.i.{weight,bias}
+ *   alpha_w/alpha_b                alpha_linear.{weight,bias}
+ *   rgb_w/rgb_b                    rgb_linear.{weight,bias}
+ * feature_linear.* exists in the state_dict but is never applied (face_nerf.py:34 vs :66)
+ * and is therefore not part of this struct.
+ */
+typedef struct idn_facenerf_params {
+    const float* pts_w[8];
+    const float* pts_b[8];
+    const float* views_w[3];
+    const float* views_b[3];
+    const float* alpha_w;
+    const float* alpha_b;
+    const float* rgb_w;
+    const float* rgb_b;
+    int dim_aud, dim_expr, dim_latent; /* widths of the per-frame conditioning vectors */
+} idn_facenerf_params;
+
+/*
+ * Re-lay the per-point part of the weights into MFMA-fragment order
+ * (`packed`, idealnerf_packed_weight_floats() floats).  Run once per weight update.
+ * Replaces nothing in the reference; it is the load-time half of
+ * FaceNeRF.forward (models/face_nerf.py:40-80).
+ */
+int idealnerf_pack_weights(const idn_facenerf_params* p, int precision, float* packed, void* stream);
+
+/*
+ * Fold the per-frame conditioning vectors into bias vectors
+ * (`folded`, idealnerf_folded_bias_floats() floats):
+ *   b0' = b0 + W0[:, 63:]  . [aud | expr/3 | latent]        (face_nerf.py:45-55,58)
+ *   b5' = b5 + W5[:, 63:63+C] . [aud | expr/3 | latent]     (face_nerf.py:61)
+ *   bv' = bv + Wv0[:, 283:] . expr/3                        (face_nerf.py:68-70)
+ * aud / expr / latent may be NULL exactly when their width is 0 (or, for expr and
+ * latent, when the caller passes None as the reference allows).  Run once per frame.
+ */
+int idealnerf_fold_conditioning(const idn_facenerf_params* p, const float* aud, const float* expr,
+                                const float* latent, float* folded, void* stream);
+
+/*
+ * FaceNeRF.forward (models/face_nerf.py:40-80): x[n, 90] = [gamma10(pts) | gamma4(dir)]
+ * -> out[n, 4] = (rgb_raw, sigma_raw).
+ */
+int idealnerf_facenerf_fwd(const float* packed, const float* folded, int precision, const float* x,
+                           int64_t n, float* out, void* stream);
+
+/*
+ * Network.run_network with the embedders fused (audio_exp_nerf.py:376-394 +
+ * helper.py:174-224): for ray r and sample s, point = o_r + d_r * z[r, s] is
+ * encoded in registers and evaluated; raw[r, s, :] = (rgb_raw, sigma_raw).
+ */
+int idealnerf_query_rays_fwd(const float* packed, const float* folded, int precision, const float* rays,
+                             const float* z, int64_t n_rays, int n_samples, float* raw, void* stream);
+
+/* Same, for callers that hold the sample points themselves (the literal signature of
+ * Network.run_network, audio_exp_nerf.py:376): pts[n_rays, n_samples, 3],
+ * viewdirs[n_rays, 3] (unit vectors, one per ray). */
+int idealnerf_query_points_fwd(const float* packed, const float* folded, int precision, const float* pts,
+                               const float* viewdirs, int64_t n_rays, int n_samples, float* raw, void* stream);
+
+/* get_rays + ray-record assembly for rows [row0, row0+nrows) of an HxW frame
+ * (helper.py:228-243, audio_exp_nerf.py:396-427; default principal point W/2,H/2 when
+ * cx/cy < 0).  c2w is 12 floats, row-major [3,4], [host] memory.  rays_out[nrows*W, 11]. */
+int idealnerf_frame_rays(const float* c2w, int H, int W, float focal, float cx, float cy, float near_, float far_,
+                         int row0, int nrows, float* rays_out, void* stream);
+
+/* Coarse depths (audio_exp_nerf.py:306-330): z[r,s] = near_r (1-t_s) + far_r t_s, with
+ * optional stratified jitter from t_rand[n_rays, n_samples] (NULL = perturb 0).
+ * t_vals[n_samples] is the caller's torch.linspace(0,1,S) buffer. */
+int idealnerf_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays,
+                            int n_samples, float* z, void* stream);
+
+/*
+ * raw2outputs (NeRFs/HeadNeRF/train/baseline.py:325-375; rgb_fg: NeRFs/TorsoNeRF/run_nerf.py:757).
+ * Any output pointer may be NULL.  weights[n_rays, n_samples].
+ */
+typedef struct idn_composite_out {
+    float* rgb_map;   /* [n,3] */
+    float* disp_map;  /* [n]   */
+    float* acc_map;   /* [n]   */
+    float* depth_map; /* [n]   */
+    float* weights;   /* [n,S] */
+    float* rgb_fg;    /* [n,3] */
+    float* last_weight; /* [n] = weights[:, -1] */
+} idn_composite_out;
+
+int idealnerf_composite_fwd(const float* raw, const float* z, const float* rays, const float* bc_rgb,
+                            int64_t n_rays, int n_samples, const idn_composite_out* out, void* stream);
+
+/*
+ * sample_pdf + merge (helper.py:269-313, audio_exp_nerf.py:340-349).
+ *   weights[n, S] are the coarse compositing weights; the kernel uses weights[:, 1:-1]
+ *   and bins = midpoints of z[n, S].
+ *   u: [n_importance] shared by all rays when u_per_ray == 0 (deterministic,
+ *      torch.linspace buffer), or [n, n_importance] when u_per_ray != 0.
+ * Outputs (each may be NULL): z_samples[n, Ni], inds[n, Ni] (int64, searchsorted
+ * right=True result), cdf[n, S-1], z_fine[n, S+Ni] (sorted union), z_std[n].
+ */
+int idealnerf_sample_pdf_fwd(const float* z, const float* weights, const float* u, int u_per_ray,
+                             int64_t n_rays, int n_samples, int n_importance, float* z_samples, int64_t* inds,
+                             float* cdf, float* z_fine, float* z_std, void* stream);
+
+/* The bit-exact boundary on its own (helper.py:297-310): given cdf[n, nb], bins[n, nb],
+ * u (as above) -> inds (int64) and z_samples. */
+int idealnerf_invert_cdf(const float* cdf, const float* bins, const float* u, int u_per_ray, int64_t n_rays,
+                         int n_bins, int n_importance, float* z_samples, int64_t* inds, void* stream);
+
+/*
+ * Network.render_rays forward (audio_exp_nerf.py:297-371), all stages on `stream`.
+ */
+typedef struct idn_render_args {
+    const float* rays;    /* [n,11] */
+    const float* bc_rgb;  /* [n,3]  */
+    int64_t n_rays;
+    int n_samples;        /* N_samples   (2..256)  */
+    int n_importance;     /* N_importance (0..256) */
+    int precision;
+    const float* packed_coarse;
+    const float* folded_coarse;
+    const float* packed_fine;   /* may be NULL when n_importance == 0 */
+    const float* folded_fine;
+    const float* t_vals;  /* [n_samples] torch.linspace(0,1,N_samples) */
+    const float* t_rand;  /* [n, n_samples] or NULL (perturb == 0) */
+    const float* u;       /* [n_importance] (u_per_ray=0) or [n, n_importance] */
+    int u_per_ray;
+    /* outputs, any may be NULL */
+    float* rgb_map;  float* disp_map;  float* acc_map;  float* depth_map;  float* last_weight;  float* rgb_fg;
+    float* rgb0;     float* disp0;     float* acc0;     float* z_std;      float* last_weight0; float* rgb_fg0;
+    /* debug taps, any may be NULL */
+    float* tap_z_coarse;   /* [n,S]     */
+    float* tap_raw_coarse; /* [n,S,4]   */
+    float* tap_weights_coarse; /* [n,S] */
+    float* tap_cdf;        /* [n,S-1]   */
+    int64_t* tap_inds;     /* [n,Ni]    */
+    float* tap_z_samples;  /* [n,Ni]    */
+    float* tap_z_fine;     /* [n,S+Ni]  */
+    float* tap_raw_fine;   /* [n,S+Ni,4]*/
+    float* tap_weights_fine; /* [n,S+Ni]*/
+    void* workspace;       /* idealnerf_render_workspace_bytes() bytes */
+    size_t workspace_bytes;
+} idn_render_args;
+
+size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
+int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream);
+
+/*
+ * Measurement aid (no reference counterpart): between begin and end, every launch of
+ * the fused PE+MLP kernel is bracketed by HIP events on its own stream.  end()
+ * synchronises those events and returns the summed kernel time, the number of launches
+ * and the number of points (ray-samples) they evaluated.  Process-wide; not for
+ * concurrent use.
+ */
+void idealnerf_profile_begin(void);
+int idealnerf_profile_end(double* total_ms, int64_t* launches, int64_t* points);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDEALNERF_H */
