@@ -27,13 +27,26 @@ FLOP_PER_SAMPLE = 1_114_368      # algorithmic, SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the cgroup quota if there is one, else the
+    affinity mask (the GPU box exposes 256 hardware threads but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("IDN_CPU_THREADS", "16")))
+
+
 def cpu_baseline(syn, pc, pf, gpu_rgb_band, band_row0, n_rays=2048):
     """The CPU oracle (a port of the reference's path, pinned to it by tests/golden) timed on
     this host on a bounded sample: the first `n_rays` rays of the frame."""
     import oracle
     W = syn["W"]
     nrows = (n_rays + W - 1) // W
-    threads = os.cpu_count() or 1
+    threads = host_cpu_share()
     torch.set_num_threads(threads)
     kw = dict(chunk=1024)
     with torch.no_grad():

@@ -185,6 +185,24 @@ def main():
         torch.searchsorted = real_ss
     np.savez(os.path.join(HERE, "sample_pdf.npz"), **fx)
 
+    # ---- a10: per-frame audio nets (models/audio_net.py); weights stored (small, torch-initialised)
+    from models.audio_net import AudioNet, AudioAttNet, DeepSpeechAudNet
+    torch.manual_seed(77)
+    fx = {}
+    auds = f32(rs.standard_normal((8, 16, 29)))
+    nets = {"aud": AudioNet(64, 16), "att": AudioAttNet(), "ds": DeepSpeechAudNet()}
+    for tag, m in nets.items():
+        m.apply(aen.init_weights)
+        for k, v in m.state_dict().items():
+            fx[f"{tag}_sd_{k}"] = v.numpy()
+    with torch.no_grad():
+        out8 = nets["aud"](auds)          # [8, 64]: the smoothing window (audio_exp_nerf.py:256)
+        out1 = nets["aud"](auds[3:4])     # [64]: the single-frame path (:259)
+        att = nets["att"](out8)           # [64]  (:257)
+        ds = nets["ds"](auds[3:4])        # [29]  (:262)
+    fx.update(aud_in=auds.numpy(), aud_out8=out8.numpy(), aud_out1=out1.numpy(), att_out=att.numpy(), ds_out=ds.numpy())
+    np.savez_compressed(os.path.join(HERE, "audio_nets.npz"), **fx)
+
     # ---- a3-a9: Network.render_rays (+ a1/a9 full-frame harness, a12 train harness) --
     dims = oracle.facenerf_dims()
     H = W = 32

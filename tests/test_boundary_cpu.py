@@ -1,0 +1,199 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly
+what include/idealnerf.h declares, the ctypes mirrors have the C layout, the host layer
+keeps the reference's names/shapes/semantics, the product path refuses CPU tensors, and
+the multi-rank tiling works over gloo with world_size 2.  No GPU compute here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "idealnerf.h")
+
+
+@pytest.fixture(scope="module")
+def idn():
+    import idealnerf_amd
+    return idealnerf_amd
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(idealnerf_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(idn):
+    lib = idn._lib.load()
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/idealnerf.h but not exported"
+    assert sorted(idn._lib.PROTOTYPES) == names, "ctypes prototypes and header are out of sync"
+    assert lib.idealnerf_version() == 1
+    assert lib.idealnerf_folded_bias_floats() == 2496
+    assert lib.idealnerf_packed_weight_floats(0) == 2304 * 256
+    assert lib.idealnerf_packed_weight_floats(99) == 0
+
+
+def test_ctypes_structs_match_c_layout(idn, tmp_path):
+    prog = tmp_path / "sz.c"
+    prog.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "idealnerf.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(idn_facenerf_params), '
+        'sizeof(idn_composite_out), sizeof(idn_render_args), offsetof(idn_facenerf_params, dim_aud), '
+        'offsetof(idn_render_args, t_vals), offsetof(idn_render_args, tap_inds), '
+        'offsetof(idn_render_args, workspace_bytes));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    L = idn._lib
+    want = [C.sizeof(L.FaceNerfParams), C.sizeof(L.CompositeOut), C.sizeof(L.RenderArgs),
+            L.FaceNerfParams.dim_aud.offset, L.RenderArgs.t_vals.offset, L.RenderArgs.tap_inds.offset,
+            L.RenderArgs.workspace_bytes.offset]
+    assert got == want
+
+
+def test_c_abi_argument_errors_without_gpu(idn):
+    lib = idn._lib.load()
+    # NULL params: rejected before any HIP call
+    assert lib.idealnerf_pack_weights(None, 0, None, None) == -1
+    assert b"NULL" in lib.idealnerf_last_error()
+    p = idn._lib.FaceNerfParams()
+    assert lib.idealnerf_pack_weights(C.byref(p), 0, None, None) == -1
+    a = idn._lib.RenderArgs()
+    a.precision = 7
+    assert lib.idealnerf_render_rays_fwd(C.byref(a), None) == -2  # IDN_EUNSUPPORTED
+    assert lib.idealnerf_render_workspace_bytes(0, 64, 128) == 0
+    per_ray = lib.idealnerf_render_workspace_bytes(1000, 64, 128) / 1000
+    assert 5000 < per_ray < 6500  # 6*S + 6*(S+Ni) floats per ray, rounded up per buffer
+    assert lib.idealnerf_render_workspace_bytes(10 ** 6, 64, 128) == lib.idealnerf_render_workspace_bytes(32768, 64, 128)
+
+
+def test_product_path_refuses_cpu_tensors(idn):
+    x = torch.zeros(4, 90)
+    with pytest.raises(idn._lib.IdealNerfError, match="GPU"):
+        idn.ops.facenerf_fwd(torch.zeros(8), torch.zeros(8), x)
+    net = idn.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76)
+    with torch.no_grad(), pytest.raises(idn._lib.IdealNerfError):
+        net(x, torch.zeros(64), torch.zeros(76), torch.zeros(32))
+
+
+def test_facenerf_state_dict_contract(idn):
+    for v in (dict(dim_aud=64, dim_expr=76, dim_latent=32), dict(dim_aud=106, dim_expr=0, dim_latent=0),
+              dict(dim_aud=64, dim_expr=0, dim_latent=0)):
+        net = idn.FaceNeRF(**v)
+        shapes = {k: tuple(t.shape) for k, t in net.state_dict().items()}
+        assert shapes == oracle.facenerf_param_shapes(oracle.facenerf_dims(**v))
+    assert "feature_linear.weight" in shapes  # never applied upstream, still part of checkpoints
+    with pytest.raises(NotImplementedError):
+        idn.FaceNeRF(D=4)
+    with pytest.raises(NotImplementedError):
+        idn.FaceNeRF(W=128)
+
+
+def test_network_contract(idn):
+    from idealnerf_amd.audio_exp_nerf import Network, init_weights
+    from idealnerf_amd.helper import RenderConfig
+    net = Network(450, 450, 1200.0, 0.3, 0.9, 8192, None, 64, 128)  # positional, typo'd N_samlpes included
+    tops = sorted(set(k.split(".")[0] for k in net.state_dict()))
+    assert tops == ["aud_att_net", "aud_net", "ds_aud_net", "face_nerf_coarse", "face_nerf_fine"]
+    ref_keys = {"aud_net.encoder_conv.0.weight", "aud_net.encoder_fc1.2.bias", "aud_att_net.attentionConvNet.8.weight",
+                "aud_att_net.attentionNet.0.weight", "ds_aud_net.encoder_fc.0.weight",
+                "face_nerf_fine.views_linears.2.bias", "face_nerf_coarse.pts_linears.5.weight"}
+    assert ref_keys <= set(net.state_dict())
+    assert net.state_dict()["face_nerf_coarse.pts_linears.5.weight"].shape == (256, 491)
+    net.apply(init_weights)
+    assert float(net.face_nerf_fine.rgb_linear.bias[0]) == pytest.approx(0.01)
+    cfg = RenderConfig()
+    assert (cfg.N_samples, cfg.N_importance, cfg.perturb, cfg.chunk, cfg.netchunk) == (64, 128, 1.0, 8192, 65536)
+
+
+def test_draw_randoms_follow_reference_rules(idn):
+    from idealnerf_amd.audio_exp_nerf import Network
+    t, u = Network.draw_randoms(5, 64, 128, 0.0, False, "cpu")
+    assert t is None and torch.equal(u, torch.linspace(0.0, 1.0, 128))
+    t, u = Network.draw_randoms(5, 64, 128, 1.0, True, "cpu")  # reference's pytest=True: numpy seed 0 for both
+    np.random.seed(0)
+    assert np.array_equal(t.numpy(), np.random.rand(5, 64).astype(np.float32))
+    np.random.seed(0)
+    assert np.array_equal(u.numpy(), np.random.rand(5, 128).astype(np.float32))
+    t, u = Network.draw_randoms(5, 64, 0, 1.0, False, "cpu")
+    assert u is None and t.shape == (5, 64)
+
+
+def test_audio_nets_match_reference(idn, golden):
+    from idealnerf_amd.models.audio_net import AudioAttNet, AudioNet, DeepSpeechAudNet
+    g = golden("audio_nets")
+    nets = {"aud": AudioNet(64, 16), "att": AudioAttNet(), "ds": DeepSpeechAudNet()}
+    for tag, m in nets.items():
+        sd = {k[len(tag) + 4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(tag + "_sd_")}
+        m.load_state_dict(sd, strict=True)
+    auds = torch.from_numpy(g["aud_in"])
+    with torch.no_grad():
+        out8 = nets["aud"](auds)
+        np.testing.assert_allclose(out8.numpy(), g["aud_out8"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(nets["aud"](auds[3:4]).numpy(), g["aud_out1"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(nets["att"](out8).numpy(), g["att_out"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(nets["ds"](auds[3:4]).numpy(), g["ds_out"], rtol=1e-5, atol=1e-6)
+
+
+def test_get_embedder_matches_golden(idn, golden):
+    from idealnerf_amd.helper import get_embedder
+    g = golden("pe")
+    for L, key in ((10, "pe10"), (4, "pe4"), (3, "pe3")):
+        fn, dim = get_embedder(L, 0)
+        out = fn(torch.from_numpy(g["x"]))
+        assert dim == g[key].shape[1]
+        np.testing.assert_array_equal(out.numpy(), g[key])
+
+
+def test_row_bands_tile_the_frame(idn):
+    from idealnerf_amd.parallel import all_bands
+    for H in (512, 450, 7, 8, 9):
+        for world in (1, 2, 3, 4, 8):
+            b = all_bands(H, world)
+            assert b[0][0] == 0 and b[-1][1] == H
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [y - x for x, y in b]
+            assert max(sizes) - min(sizes) <= 1
+    assert all_bands(512, 8) == [(64 * r, 64 * r + 64) for r in range(8)]
+
+
+def _gloo_worker(rank, world, H, port, ok):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from idealnerf_amd.parallel import gather_rows, row_band
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        W = 6
+        full = torch.arange(H * W * 3, dtype=torch.float32).reshape(H, W, 3)
+        r0, r1 = row_band(H, rank, world)
+        out = gather_rows(full[r0:r1].clone(), H)
+        ok[rank] = int(torch.equal(out, full))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [8, 9])
+def test_gather_rows_gloo_two_ranks(H):
+    """N>1 path on CPU: two ranks render disjoint row bands and all-gather them (even and
+    uneven split)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ok = ctx.Array("i", [0, 0])
+    port = 29500 + (os.getpid() + H) % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, H, port, ok)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert list(ok) == [1, 1]
