@@ -40,7 +40,7 @@ def host_cpu_share():
     return min(n, int(os.environ.get("IDN_CPU_THREADS", "16")))
 
 
-def cpu_baseline(syn, pc, pf, gpu_rgb_band, band_row0, n_rays=2048):
+def cpu_baseline(syn, pc, pf, gpu_rgb_band, band_row0, n_rays=8192):
     """The CPU oracle (a port of the reference's path, pinned to it by tests/golden) timed on
     this host on a bounded sample: the first `n_rays` rays of the frame."""
     import oracle
