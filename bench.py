@@ -139,6 +139,16 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the
+        # process, so the figure comes from the committed rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r01_pmc_mlp_f32.json).
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mlp_f32.json")))
+            if H == 512 and world == 1:
+                traffic = pmc["hbm_traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         samples = H * W * (S + S + Ni) * args.steps
         value = samples / dt
         ach = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12 if k_ms.value > 0 else None
@@ -153,7 +163,7 @@ def main():
                        "partition": f"{world} row band(s) + RCCL all_gather of rgb tiles" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)",
                          "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None, "traffic": None,
+                         "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None, "traffic": traffic,
                          "launches": k_n.value, "avg_launch_ms": (k_ms.value / k_n.value) if k_n.value else None,
                          "flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": (k_pts.value / k_n.value) if k_n.value else None,
                          "kernel_time_share": (k_ms.value * 1e-3) / dt if dt > 0 else None},
