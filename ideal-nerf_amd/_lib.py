@@ -23,6 +23,11 @@ class FaceNerfParams(C.Structure):
                 ("dim_aud", C.c_int), ("dim_expr", C.c_int), ("dim_latent", C.c_int)]
 
 
+class FaceNerfGrads(C.Structure):
+    _fields_ = [("pts_w", fp * 8), ("pts_b", fp * 8), ("views_w", fp * 3), ("views_b", fp * 3),
+                ("alpha_w", fp), ("alpha_b", fp), ("rgb_w", fp), ("rgb_b", fp)]
+
+
 class CompositeOut(C.Structure):
     _fields_ = [(n, fp) for n in ("rgb_map", "disp_map", "acc_map", "depth_map", "weights", "rgb_fg", "last_weight")]
 
@@ -58,6 +63,11 @@ PROTOTYPES = {
     "idealnerf_invert_cdf": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp]),
     "idealnerf_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "idealnerf_render_rays_fwd": (C.c_int, [C.POINTER(RenderArgs), fp]),
+    "idealnerf_train_acts_floats": (C.c_size_t, [C.c_int64]),
+    "idealnerf_query_rays_train_fwd": (C.c_int, [fp, fp, C.c_int, fp, fp, C.c_int64, C.c_int, fp, fp, fp]),
+    "idealnerf_pass_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "idealnerf_pass_bwd": (C.c_int, [C.POINTER(FaceNerfParams), C.POINTER(FaceNerfGrads), fp, fp, fp, fp, fp, fp, fp,
+                                     fp, C.c_int64, C.c_int, fp, fp, fp, fp, fp, fp, fp, C.c_size_t, fp]),
     "idealnerf_profile_begin": (None, []),
     "idealnerf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }

@@ -96,6 +96,14 @@ class Network(nn.Module):
     def render_rays(self, rays, bc_rgb, aud_para, poses, latent_code, expr, retraw=False, lindisp=False,
                     perturb=None, white_bkgd=False, raw_noise_std=0., attention_embed_ln=0, pytest=False,
                     taps=False):
+        return self._render(rays, bc_rgb, aud_para, latent_code, expr, self.face_nerf_coarse, self.face_nerf_fine,
+                            False, retraw, lindisp, perturb, white_bkgd, raw_noise_std, pytest, taps)
+
+    def _render(self, rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg, retraw=False, lindisp=False,
+                perturb=None, white_bkgd=False, raw_noise_std=0., pytest=False, taps=False):
+        """Shared body of render_rays for the head pair and the torso pair of networks
+        (``with_fg`` adds the torso variant's rgb_map_fg / rgb_map_fg0 / last_weight0,
+        NeRFs/TorsoNeRF/train_torso.py:326-345)."""
         args = self.args
         perturb = args.perturb if perturb is None else perturb
         if lindisp or white_bkgd or raw_noise_std > 0.:
@@ -103,24 +111,30 @@ class Network(nn.Module):
                                       "(audio_exp_nerf.py:279,297-299) and are not compiled")
         if torch.is_grad_enabled() and self.training:
             from .autograd import render_rays_apply
-            return render_rays_apply(self, rays, bc_rgb, aud_para, latent_code, expr, perturb, pytest)
+            return render_rays_apply(self, coarse, fine, rays, bc_rgb, aud_para, latent_code, expr, perturb, pytest,
+                                     with_fg)
         rays = rays.to(torch.float32).contiguous()
         bc_rgb = bc_rgb.to(torch.float32).contiguous()
         n, dev = rays.shape[0], rays.device
         S, Ni = args.N_samples, args.N_importance
         t_rand, u = self.draw_randoms(n, S, Ni, perturb, pytest, dev)
         with torch.no_grad():
-            fc = self.face_nerf_coarse.folded_bias(aud_para, expr, latent_code)
-            ff = self.face_nerf_fine.folded_bias(aud_para, expr, latent_code) if Ni > 0 else None
-            out = ops.render_rays_fwd(rays, bc_rgb, self.face_nerf_coarse.packed_weights(), fc,
-                                      self.face_nerf_fine.packed_weights() if Ni > 0 else None, ff,
-                                      linspace01(S, dev), u, Ni, t_rand=t_rand, taps=taps or retraw)
+            fc = coarse.folded_bias(aud_para, expr, latent_code)
+            ff = fine.folded_bias(aud_para, expr, latent_code) if Ni > 0 else None
+            out = ops.render_rays_fwd(rays, bc_rgb, coarse.packed_weights(), fc,
+                                      fine.packed_weights() if Ni > 0 else None, ff,
+                                      linspace01(S, dev), u, Ni, t_rand=t_rand, with_fg=with_fg, taps=taps or retraw)
         ret = {'rgb_map': out['rgb_map'], 'disp_map': out['disp_map'], 'acc_map': out['acc_map']}
+        if with_fg:
+            ret['rgb_map_fg'] = out['rgb_fg']
         if retraw:
             ret['raw'] = out['tap_raw_fine'] if Ni > 0 else out['tap_raw_coarse']
         if Ni > 0:
             for k in ('rgb0', 'disp0', 'acc0', 'z_std', 'last_weight'):
                 ret[k] = out[k]
+            if with_fg:
+                ret['last_weight0'] = out['last_weight0']
+                ret['rgb_map_fg0'] = out['rgb_fg0']
         if taps:
             ret.update({k: v for k, v in out.items() if k.startswith('tap_')})
         return ret

@@ -161,6 +161,56 @@ int idealnerf_invert_cdf(const float* cdf, const float* bins, const float* u, in
                              inds, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
+size_t idealnerf_train_acts_floats(int64_t n_points) {
+    if (n_points <= 0) return 0;
+    return (size_t)((n_points + 127) / 128 * 128) * kActCols;
+}
+
+int idealnerf_query_rays_train_fwd(const float* packed, const float* folded, int precision, const float* rays,
+                                   const float* z, int64_t n_rays, int n_samples, float* raw, float* acts,
+                                   void* stream) {
+    if (int e = check_precision(precision)) return e;
+    if (n_rays < 0 || n_samples < 1) return fail(IDN_EINVAL, "bad sizes");
+    if (n_rays == 0) return IDN_OK;
+    if (!packed || !folded || !rays || !z || !raw || !acts) return fail(IDN_EINVAL, "NULL pointer");
+    const int64_t n = n_rays * n_samples;
+    const int64_t p_pad = (n + 127) / 128 * 128;
+    if (p_pad > n)  // rows the kernel never writes must read as zero in the backward GEMMs
+        for (int i = 0; i < kActCount; ++i)
+            IDN_HIP_CHECK(hipMemsetAsync(acts + (size_t)act_off(i) * p_pad + (size_t)n * act_width(i), 0,
+                                         (size_t)(p_pad - n) * act_width(i) * sizeof(float), (hipStream_t)stream));
+    return launch_mlp_f32(packed, folded, nullptr, rays, z, nullptr, nullptr, n, n_samples, raw, (hipStream_t)stream,
+                          acts, p_pad);
+}
+
+size_t idealnerf_pass_bwd_workspace_bytes(int64_t n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    return bwd_workspace_bytes(n_rays * n_samples);
+}
+
+int idealnerf_pass_bwd(const idn_facenerf_params* p, const idn_facenerf_grads* grads, const float* aud,
+                       const float* expr, const float* latent, const float* acts, const float* raw, const float* z,
+                       const float* rays, const float* bc_rgb, int64_t n_rays, int n_samples, const float* g_rgb_map,
+                       const float* g_rgb_fg, const float* g_last_weight, const float* g_acc, float* d_aud,
+                       float* d_latent, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = check_params(p)) return e;
+    if (!grads) return fail(IDN_EINVAL, "grads is NULL");
+    for (int i = 0; i < 8; ++i)
+        if (!grads->pts_w[i] || !grads->pts_b[i]) return fail(IDN_EINVAL, "grad pts_linears.%d is NULL", i);
+    for (int i = 0; i < 3; ++i)
+        if (!grads->views_w[i] || !grads->views_b[i]) return fail(IDN_EINVAL, "grad views_linears.%d is NULL", i);
+    if (!grads->alpha_w || !grads->alpha_b || !grads->rgb_w || !grads->rgb_b) return fail(IDN_EINVAL, "grad head is NULL");
+    if ((p->dim_aud > 0) != (aud != nullptr) || (p->dim_expr > 0) != (expr != nullptr) ||
+        (p->dim_latent > 0) != (latent != nullptr))
+        return fail(IDN_EINVAL, "conditioning pointers do not match the widths");
+    if (n_rays < 0) return fail(IDN_EINVAL, "n_rays < 0");
+    if (n_rays == 0) return IDN_OK;
+    if (!acts || !raw || !z || !rays || !bc_rgb) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_pass_bwd(*p, *grads, aud, expr, latent, acts, raw, z, rays, bc_rgb, n_rays, n_samples, g_rgb_map,
+                           g_rgb_fg, g_last_weight, g_acc, d_aud, d_latent, workspace, workspace_bytes,
+                           (hipStream_t)stream);
+}
+
 void idealnerf_profile_begin(void) {
     g_prof_n = 0;
     g_prof_on = true;

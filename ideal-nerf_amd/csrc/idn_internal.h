@@ -63,6 +63,25 @@ static_assert(kBiasFloats == 2496, "bias table changed");
 constexpr int kSigmaChannel = 128;
 
 // ---------------------------------------------------------------------------
+// Training-mode activation slab: layer-major row-major matrices of p_pad rows each
+// (p_pad = n_points rounded up to 128; rows beyond n_points stay zero).
+//   x0  [p_pad, 64]   gamma10(point), column 63 zero
+//   dir [p_pad, 64]   gamma4(view dir) in columns 0..26, rest zero
+//   a1..a8 [p_pad, 256]  post-ReLU outputs of pts_linears.0..7
+//   v1..v3 [p_pad, 128]  post-ReLU outputs of views_linears.0..2
+// act_off(i) = first column of matrix i when the slab is viewed as 2560 columns.
+// ---------------------------------------------------------------------------
+enum { kActX0 = 0, kActDir = 1, kActA1 = 2, kActV1 = 10, kActCount = 13 };
+constexpr int act_width(int i) { return i < 2 ? 64 : (i < kActV1 ? 256 : 128); }
+constexpr int act_off(int i) {
+    int o = 0;
+    for (int k = 0; k < i; ++k) o += act_width(k);
+    return o;
+}
+constexpr int kActCols = act_off(kActCount);  // 2560
+static_assert(kActCols == 2560, "activation slab layout changed");
+
+// ---------------------------------------------------------------------------
 // error plumbing (capi.hip)
 // ---------------------------------------------------------------------------
 int fail(int code, const char* fmt, ...);
@@ -91,7 +110,8 @@ int launch_fold(const idn_facenerf_params& p, const float* aud, const float* exp
 // x != nullptr: pre-embedded rows [n_points, 90]; pts != nullptr: raw points [n_points,3] +
 // dirs[n_points/S, 3]; else rays[n_rays,11] + z[n_rays,S]
 int launch_mlp_f32(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
-                   const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
+                   const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s,
+                   float* acts = nullptr, int64_t p_pad = 0);
 
 int launch_frame_rays(const float* c2w, int H, int W, float focal, float cx, float cy, float near_, float far_,
                       int row0, int nrows, float* rays_out, hipStream_t s);
@@ -102,5 +122,12 @@ int launch_composite(const float* raw, const float* z, const float* rays, const 
 int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in, const float* bins_in,
                       const float* u, int u_per_ray, int64_t n_rays, int S, int Ni, float* z_samples,
                       int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s);
+
+// train.hip: backward of one render pass
+size_t bwd_workspace_bytes(int64_t n_points);
+int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, const float* aud, const float* expr,
+                    const float* latent, const float* acts, const float* raw, const float* z, const float* rays,
+                    const float* bc, int64_t n_rays, int S, const float* g_rgb, const float* g_fg, const float* g_lw,
+                    const float* g_acc, float* d_aud, float* d_latent, void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace idn

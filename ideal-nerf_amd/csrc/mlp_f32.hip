@@ -190,15 +190,47 @@ struct MlpArgs {
     long n_points;
     int S;
     float* raw;         // [n_points, 4]
+    float* acts;        // training only: activation slab (act_off() matrices of p_pad rows), else null
+    long p_pad;
 };
 
 constexpr int kMlpLds = kRingFrags * kFragBytes + kBiasFloats * 4;
+constexpr int kStagePitch = 33;                       // 32x32 transpose tile, conflict-free
+constexpr int kStageFloats = 32 * kStagePitch;
+constexpr int kMlpLdsTrain = kMlpLds + 4 * kStageFloats * 4;
 
-template <int MODE>
+// Training: write NT post-ReLU accumulator tiles (channel = register, point = lane) as rows
+// of a row-major [p_pad, ld] matrix: transpose each 32x32 tile through a per-wave LDS patch
+// so that every global store instruction writes two full 128-byte row segments.
+template <int NT>
+__device__ __forceinline__ void save_tiles(const f32x16 (&t)[NT], float* dst, int ld, long p0, long n_points,
+                                           float* stage, int lane) {
+    const int m = lane & 31, h = lane >> 5;
+    static_for<NT>([&](auto T) {
+        constexpr int tt = decltype(T)::value;
+        static_for<16>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            stage[m * kStagePitch + (r & 3) + 8 * (r >> 2) + 4 * h] = t[tt][r];
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        static_for<16>([&](auto RR) {
+            constexpr int rr = decltype(RR)::value;
+            const int row = 2 * rr + h;
+            const float v = stage[row * kStagePitch + m];
+            if (p0 + row < n_points) dst[(p0 + row) * ld + 32 * tt + m] = v;
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    });
+}
+
+template <int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     float* bias_s = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes);
+    float* stage = reinterpret_cast<float*>(smem + kMlpLds) + (threadIdx.x >> 6) * kStageFloats;  // SAVE only
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -280,6 +312,31 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
             });
         }
 
+        const long p0 = tile * 128 + wave * 32;  // first point of this wave
+        if constexpr (SAVE) {
+            if (valid) {
+                float* x0 = a.acts + act_off(kActX0) * a.p_pad + P * 64 + 4 * h;
+                float* dr = a.acts + act_off(kActDir) * a.p_pad + P * 64 + 4 * h;
+                static_for<8>([&](auto G) {
+                    constexpr int g = decltype(G)::value;
+                    f32x4 v = {pe[g][0], pe[g][1], pe[g][2], pe[g][3]};
+                    *reinterpret_cast<f32x4*>(x0 + 8 * g) = v;
+                });
+                static_for<8>([&](auto G) {
+                    constexpr int g = decltype(G)::value;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (g < 4) v = f32x4{pd[g][0], pd[g][1], pd[g][2], pd[g][3]};
+                    *reinterpret_cast<f32x4*>(dr + 8 * g) = v;
+                });
+            }
+        }
+        auto save_hid = [&](const f32x16 (&t)[8], int layer /*1..8*/) {
+            if constexpr (SAVE) save_tiles<8>(t, a.acts + act_off(kActA1 + layer - 1) * a.p_pad, 256, p0, a.n_points, stage, lane);
+        };
+        auto save_hv = [&](const f32x16 (&t)[4], int layer /*1..3*/) {
+            if constexpr (SAVE) save_tiles<4>(t, a.acts + act_off(kActV1 + layer - 1) * a.p_pad, 128, p0, a.n_points, stage, lane);
+        };
+
         auto pe_get = [&](auto G, auto J) { return pe[decltype(G)::value][decltype(J)::value]; };
 
         f32x16 acc[8], hid[8];
@@ -292,12 +349,14 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         load_bias<8>(acc, bias_h + bias_off(0));
         run_layer<layer_f0(0), 8, 8>(acc, pe_get, ws, ring_lane);
         relu_to<8>(hid, acc);
+        save_hid(hid, 1);
         // ---- pts_linears.1..4 : 256 -> 256
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
             load_bias<8>(acc, bias_h + l * 256);
             run_layer<layer_f0(1), 8, 32>(acc, hid_get, ws, ring_lane);
             relu_to<8>(hid, acc);
+            save_hid(hid, l + 1);
         }
         // ---- pts_linears.5 : [PE(64) | 256] -> 256   (skip connection, face_nerf.py:61-62)
         load_bias<8>(acc, bias_h + bias_off(5));
@@ -310,12 +369,14 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
             },
             ws, ring_lane);
         relu_to<8>(hid, acc);
+        save_hid(hid, 6);
         // ---- pts_linears.6..7
 #pragma unroll 1
         for (int l = 6; l <= 7; ++l) {
             load_bias<8>(acc, bias_h + l * 256);
             run_layer<layer_f0(6), 8, 32>(acc, hid_get, ws, ring_lane);
             relu_to<8>(hid, acc);
+            save_hid(hid, l + 1);
         }
         // ---- views_linears.0 (+ alpha_linear as channel 128) : [256 | dirPE(32)] -> 160
         f32x16 va[5];
@@ -334,6 +395,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
             constexpr int t = decltype(T)::value;
             static_for<16>([&](auto R) { hv[t][decltype(R)::value] = fmaxf(va[t][decltype(R)::value], 0.0f); });
         });
+        save_hv(hv, 1);
         auto hv_get = [&](auto G, auto J) {
             constexpr int g = decltype(G)::value, j = decltype(J)::value;
             return hv[g >> 2][(g & 3) * 4 + j];
@@ -342,9 +404,11 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         load_bias<4>(vb, bias_h + bias_off(9));
         run_layer<layer_f0(9), 4, 16>(vb, hv_get, ws, ring_lane);
         relu_to<4>(hv, vb);
+        save_hv(hv, 2);
         load_bias<4>(vb, bias_h + bias_off(10));
         run_layer<layer_f0(10), 4, 16>(vb, hv_get, ws, ring_lane);
         relu_to<4>(hv, vb);
+        save_hv(hv, 3);
         // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile)
         f32x16 rgb[1];
         load_bias<1>(rgb, bias_h + bias_off(11));
@@ -366,7 +430,8 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
 }
 
 int launch_mlp_f32(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
-                   const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s) {
+                   const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s,
+                   float* acts, int64_t p_pad) {
     if (n_points <= 0) return IDN_OK;
     static int num_cu = 0;
     if (!num_cu) {
@@ -375,23 +440,28 @@ int launch_mlp_f32(const float* packed, const float* folded, const float* x, con
         hipDeviceProp_t prop;
         IDN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         num_cu = prop.multiProcessorCount;
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeRays>),
+        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeRays, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeX>),
+        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeX, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModePts>),
+        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModePts, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeRays, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLdsTrain));
     }
     const int64_t ntiles = (n_points + 127) / 128;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
-    MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw};
+    MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, acts, (long)p_pad};
     ProfScope prof(s, n_points);
-    if (x)
-        hipLaunchKernelGGL(mlp_f32_kernel<kModeX>, dim3(grid), dim3(256), kMlpLds, s, a);
+    if (acts) {
+        if (x || pts) return fail(IDN_EUNSUPPORTED, "activation saving is only built for the rays+z input mode");
+        hipLaunchKernelGGL((mlp_f32_kernel<kModeRays, true>), dim3(grid), dim3(256), kMlpLdsTrain, s, a);
+    } else if (x)
+        hipLaunchKernelGGL((mlp_f32_kernel<kModeX, false>), dim3(grid), dim3(256), kMlpLds, s, a);
     else if (pts)
-        hipLaunchKernelGGL(mlp_f32_kernel<kModePts>, dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((mlp_f32_kernel<kModePts, false>), dim3(grid), dim3(256), kMlpLds, s, a);
     else
-        hipLaunchKernelGGL(mlp_f32_kernel<kModeRays>, dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((mlp_f32_kernel<kModeRays, false>), dim3(grid), dim3(256), kMlpLds, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

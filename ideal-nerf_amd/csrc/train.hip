@@ -1,0 +1,554 @@
+// Backward of one render pass (coarse or fine) for the training step
+// (NeRFs/HeadNeRF/train/audio_exp_nerf.py:534-552: loss.backward() through raw2outputs,
+// FaceNeRF and the per-frame conditioning).  gfx950, fp32 MFMA.
+//
+//   composite_bwd     d(rgb_map, rgb_fg, last_weight, acc) -> d raw           (one wave per ray)
+//   gemm_nn           delta_{l-1} = (delta_l . W_l) (.) [a_{l-1} > 0]          (rows = points)
+//   gemm_tn           dW_l = delta_l^T . a_{l-1}, contraction over points, split over workgroups
+//   reduce_partials   sums the per-split dW blocks into the gradient tensors
+//   colsum            db_l = sum_p delta_l
+//   fold_bwd          conditioning columns of W0 / W5 / Wv0 and d aud, d latent
+//
+// Activations come from the training variant of the MLP kernel as row-major matrices
+// (idn_internal.h, "activation slab").  Everything is deterministic: no float atomics.
+#include "idn_internal.h"
+
+namespace idn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int d_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// ---------------------------------------------------------------------------
+// NN GEMM: C[M x N] = (A[M x K] . B[K x N]) masked.  M = points (multiple of 128),
+// N multiple of 64, K multiple of 32.  B is a window of a weight matrix: rows >= b_rows
+// read as zero, except row `extra_at` which reads `extra` (alpha_linear riding in views0).
+// ---------------------------------------------------------------------------
+struct NNArgs {
+    const float* A; int lda;
+    const float* B; int ldb; int b_rows; const float* extra; int extra_at;
+    float* C; int ldc;
+    const float* mask; int ldm;
+    int K;
+};
+constexpr int kNNPitchA = 36;  // 128 x 32 A tile, ds_read_b128 conflict-free (pitch = 4 mod 32 dwords)
+
+__global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[128 * kNNPitchA];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const long m0 = (long)blockIdx.x * 128;
+    const int n0 = blockIdx.y * 64;
+    f32x16 acc[2];
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+
+    for (int k0 = 0; k0 < g.K; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q, row = idx >> 3, ch = idx & 7;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g.A + (m0 + row) * g.lda + k0 + ch * 4);
+            *reinterpret_cast<f32x4*>(&As[row * kNNPitchA + ch * 4]) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + 256 * q, row = idx >> 6, col = idx & 63;
+            const int kk = k0 + row;
+            float v = 0.f;
+            if (kk < g.b_rows) v = g.B[(long)kk * g.ldb + n0 + col];
+            else if (g.extra && kk == g.extra_at) v = g.extra[n0 + col];
+            Bs[row * 64 + col] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[(32 * w + i) * kNNPitchA + 8 * gg + 4 * hh]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 8 * gg + 4 * hh + j;
+                acc[0] = mfma32(a4[j], Bs[c * 64 + i], acc[0]);
+                acc[1] = mfma32(a4[j], Bs[c * 64 + 32 + i], acc[1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = m0 + 32 * w + d_row(r, hh);
+            const int col = n0 + 32 * nt + i;
+            float v = acc[nt][r];
+            if (g.mask) v = g.mask[row * g.ldm + col] > 0.f ? v : 0.f;
+            g.C[row * g.ldc + col] = v;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// TN GEMM: part[split][n][k] = sum_{p in split} A[p][n0+n] * B[p][k0+k]
+// Block = (64*NTW) x (64*KTW) outputs, waves 2 x 2, contraction chunk 32 points.
+// ---------------------------------------------------------------------------
+struct TNArgs {
+    const float* A; int lda;   // delta  [P, >= N]
+    const float* B; int ldb;   // acts   [P, >= K]
+    float* part;               // [splits][N][K]
+    int N, K;
+    long P;                    // rows (multiple of 32)
+    int chunks_per_split;      // 32-row chunks per split
+};
+
+template <int NTW, int KTW>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
+    constexpr int BN = 64 * NTW, BK = 64 * KTW;
+    __shared__ __attribute__((aligned(16))) float As[32 * BN];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * BK];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int wr = w >> 1, wc = w & 1;
+    const int n0 = blockIdx.x * BN, k0 = blockIdx.y * BK;
+    const int split = blockIdx.z;
+    f32x16 acc[NTW][KTW];
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int b = 0; b < KTW; ++b)
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const long c_begin = (long)split * g.chunks_per_split;
+    long c_end = c_begin + g.chunks_per_split;
+    const long c_total = g.P / 32;
+    if (c_end > c_total) c_end = c_total;
+    for (long c = c_begin; c < c_end; ++c) {
+        const long p0 = c * 32;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BN / 32; ++q) {
+            const int idx = tid + 256 * q, row = idx / (BN / 4), ch = idx % (BN / 4);
+            *reinterpret_cast<f32x4*>(&As[row * BN + ch * 4]) =
+                *reinterpret_cast<const f32x4*>(g.A + (p0 + row) * g.lda + n0 + ch * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < BK / 32; ++q) {
+            const int idx = tid + 256 * q, row = idx / (BK / 4), ch = idx % (BK / 4);
+            *reinterpret_cast<f32x4*>(&Bs[row * BK + ch * 4]) =
+                *reinterpret_cast<const f32x4*>(g.B + (p0 + row) * g.ldb + k0 + ch * 4);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int prow = 2 * s + hh;
+            float a[NTW], b[KTW];
+#pragma unroll
+            for (int x = 0; x < NTW; ++x) a[x] = As[prow * BN + 32 * NTW * wr + 32 * x + i];
+#pragma unroll
+            for (int y = 0; y < KTW; ++y) b[y] = Bs[prow * BK + 32 * KTW * wc + 32 * y + i];
+#pragma unroll
+            for (int x = 0; x < NTW; ++x)
+#pragma unroll
+                for (int y = 0; y < KTW; ++y) acc[x][y] = mfma32(a[x], b[y], acc[x][y]);
+        }
+    }
+    float* out = g.part + (long)split * g.N * g.K;
+#pragma unroll
+    for (int x = 0; x < NTW; ++x)
+#pragma unroll
+        for (int y = 0; y < KTW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 32 * NTW * wr + 32 * x + d_row(r, hh);
+                const int k = k0 + 32 * KTW * wc + 32 * y + i;
+                out[(long)n * g.K + k] = acc[x][y][r];
+            }
+}
+
+// out[n*ldo + k] = sum_s part[s][n][k],  n < rows, k < cols  (rows/cols may be smaller than N/K: padding dropped)
+__global__ void reduce_partials_kernel(const float* part, int splits, int N, int K, float* out, int ldo, int rows,
+                                       int cols) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int n = idx / cols, k = idx % cols;
+    double s = 0.0;
+    for (int sp = 0; sp < splits; ++sp) s += (double)part[((long)sp * N + n) * K + k];
+    out[(long)n * ldo + k] = (float)s;
+}
+
+// part[blk][c] = sum over the block's rows of A[p][c]
+__global__ void colsum_kernel(const float* A, int lda, long P, int C, long rows_per_block, float* part) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const long p0 = (long)blockIdx.x * rows_per_block;
+    long p1 = p0 + rows_per_block;
+    if (p1 > P) p1 = P;
+    double s = 0.0;
+    for (long p = p0; p < p1; ++p) s += (double)A[p * lda + c];
+    part[(long)blockIdx.x * C + c] = (float)s;
+}
+
+// ---------------------------------------------------------------------------
+// compositing backward (baseline.py:325-375 differentiated; cumprod's gradient as
+// PyTorch computes it when no factor is zero: reverse cumsum(grad * out) / input).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_up_dd(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, delta, 64);
+    hi = __shfl_up(hi, delta, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_dd(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+
+struct CompBwdArgs {
+    const float4* raw; const float* z; const float* rays; const float* bc;
+    const float* g_rgb;  // [n,3] d rgb_map (may be null)
+    const float* g_fg;   // [n,3] d rgb_fg  (may be null)
+    const float* g_lw;   // [n]   d last_weight (may be null)
+    const float* g_acc;  // [n]   d acc_map (may be null)
+    float* d_rgb; int ld_rgb;    // row p = ray*S+s: d raw_rgb at d_rgb[p*ld_rgb + 0..2]
+    float* d_sig; int ld_sig;    // d raw_sigma at d_sig[p*ld_sig]
+    long n_rays; int S;
+};
+
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;
+    const int S = a.S;
+    const float* rr = a.rays + ray * IDN_RAY_FLOATS;
+    const float dn = sqrtf((rr[3] * rr[3] + rr[4] * rr[4]) + rr[5] * rr[5]);
+    const float4* rawr = a.raw + ray * S;
+    const float* zr = a.z + ray * S;
+    float gr = 0, gg = 0, gb = 0, fr = 0, fg = 0, fb = 0, glw = 0, gacc = 0;
+    if (a.g_rgb) { gr = a.g_rgb[ray * 3]; gg = a.g_rgb[ray * 3 + 1]; gb = a.g_rgb[ray * 3 + 2]; }
+    if (a.g_fg) { fr = a.g_fg[ray * 3]; fg = a.g_fg[ray * 3 + 1]; fb = a.g_fg[ray * 3 + 2]; }
+    if (a.g_lw) glw = a.g_lw[ray];
+    if (a.g_acc) gacc = a.g_acc[ray];
+
+    float zs[SPL + 1];
+    float4 rw[SPL];
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        zs[i] = s < S ? zr[s] : 0.f;
+        rw[i] = s < S ? rawr[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    zs[SPL] = __shfl_down(zs[0], 1, 64);
+    float alpha[SPL], tf[SPL], ex[SPL], dist[SPL];
+    double local = 1.0;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        float d = (s >= S - 1) ? 1e10f : (zs[i + 1] - zs[i]);
+        d = d * dn;
+        const float e = expf(-(fmaxf(rw[i].w, 0.0f) + 1e-6f) * d);
+        dist[i] = d;
+        ex[i] = e;
+        alpha[i] = (s < S) ? 1.0f - e : 0.0f;
+        tf[i] = (s < S) ? (1.0f - (1.0f - e)) + 1e-10f : 1.0f;
+        local *= (double)tf[i];
+    }
+    // exclusive prefix product over lanes
+    double incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = shfl_up_dd(incl, d);
+        if (lane >= d) incl *= o;
+    }
+    double run = shfl_up_dd(incl, 1);
+    if (lane == 0) run = 1.0;
+    float T[SPL], w[SPL], dw[SPL], cr[SPL], cg[SPL], cb[SPL];
+    double lsum = 0.0;  // sum of dw*w over this lane's samples
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        T[i] = (float)run;
+        w[i] = alpha[i] * T[i];
+        run *= (double)tf[i];
+        dw[i] = 0.f;
+        cr[i] = cg[i] = cb[i] = 0.f;
+        if (s < S) {
+            if (s == S - 1) {
+                cr[i] = a.bc[ray * 3]; cg[i] = a.bc[ray * 3 + 1]; cb[i] = a.bc[ray * 3 + 2];
+                dw[i] = (gr * cr[i] + gg * cg[i] + gb * cb[i]) + glw + gacc;
+            } else {
+                cr[i] = 1.0f / (1.0f + expf(-rw[i].x));
+                cg[i] = 1.0f / (1.0f + expf(-rw[i].y));
+                cb[i] = 1.0f / (1.0f + expf(-rw[i].z));
+                dw[i] = ((gr + fr) * cr[i] + (gg + fg) * cg[i] + (gb + fb) * cb[i]) + gacc;
+            }
+            lsum += (double)dw[i] * (double)w[i];
+        }
+    }
+    // suffix sums of dw*w: total - inclusive prefix
+    double pin = lsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = shfl_up_dd(pin, d);
+        if (lane >= d) pin += o;
+    }
+    double total = lsum;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) total += shfl_xor_dd(total, m);
+    double before = pin - lsum;  // sum over earlier lanes
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane * SPL + i;
+        if (s < S) {
+            before += (double)dw[i] * (double)w[i];          // inclusive up to s
+            const double suffix = total - before;            // sum_{t > s} dw_t w_t
+            const float dalpha = dw[i] * T[i] - (float)(suffix / (double)tf[i]);
+            const float dsig = (rw[i].w > 0.f) ? dalpha * ex[i] * dist[i] : 0.f;
+            const long p = ray * S + s;
+            a.d_sig[p * a.ld_sig] = dsig;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            if (s < S - 1) {
+                d0 = w[i] * (gr + fr) * cr[i] * (1.0f - cr[i]);
+                d1 = w[i] * (gg + fg) * cg[i] * (1.0f - cg[i]);
+                d2 = w[i] * (gb + fb) * cb[i] * (1.0f - cb[i]);
+            }
+            a.d_rgb[p * a.ld_rgb + 0] = d0;
+            a.d_rgb[p * a.ld_rgb + 1] = d1;
+            a.d_rgb[p * a.ld_rgb + 2] = d2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conditioning fold backward
+//   dW0[:, 63+c] = db0'[n] cond[c];  dW5[:, 63+c] = db5'[n] cond[c];  dWv0[:, 283+e] = dbv'[n] expr3[e]
+//   d cond[c] = sum_n W0[n][63+c] db0'[n] + W5[n][63+c] db5'[n]   -> d aud, d latent (accumulated)
+// ---------------------------------------------------------------------------
+struct FoldBwdArgs {
+    idn_facenerf_params p;
+    const float* aud; const float* expr; const float* latent;
+    const float* db0; const float* db5; const float* dbv;  // [256], [256], [128]
+    float* gW0; float* gW5; float* gWv0;                    // gradient tensors (full nn.Linear layout)
+    float* d_aud; float* d_latent;                          // accumulated (+=), may be null
+};
+__device__ __forceinline__ float cond_val(const FoldBwdArgs& d, int c) {
+    if (c < d.p.dim_aud) return d.aud[c];
+    c -= d.p.dim_aud;
+    if (c < d.p.dim_expr) return d.expr[c] * 1.0f / 3.0f;
+    c -= d.p.dim_expr;
+    return d.latent[c];
+}
+__global__ void fold_bwd_kernel(FoldBwdArgs d) {
+    const int C = d.p.dim_aud + d.p.dim_expr + d.p.dim_latent;
+    const int ld0 = IDN_PTS_CH + C, ld5 = IDN_PTS_CH + C + IDN_W, ldv = IDN_W + IDN_VIEWS_CH + d.p.dim_expr;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_outer = IDN_W * C;
+    if (idx < n_outer) {
+        const int n = idx / C, c = idx % C;
+        const float cv = cond_val(d, c);
+        d.gW0[(long)n * ld0 + IDN_PTS_CH + c] = d.db0[n] * cv;
+        d.gW5[(long)n * ld5 + IDN_PTS_CH + c] = d.db5[n] * cv;
+    } else if (idx < n_outer + (IDN_W / 2) * d.p.dim_expr) {
+        const int k = idx - n_outer, n = k / d.p.dim_expr, e = k % d.p.dim_expr;
+        d.gWv0[(long)n * ldv + IDN_W + IDN_VIEWS_CH + e] = d.dbv[n] * (d.expr[e] * 1.0f / 3.0f);
+    } else {
+        const int c = idx - n_outer - (IDN_W / 2) * d.p.dim_expr;
+        if (c >= C) return;
+        double s = 0.0;
+        for (int n = 0; n < IDN_W; ++n)
+            s += (double)d.p.pts_w[0][(long)n * ld0 + IDN_PTS_CH + c] * (double)d.db0[n] +
+                 (double)d.p.pts_w[5][(long)n * ld5 + IDN_PTS_CH + c] * (double)d.db5[n];
+        if (c < d.p.dim_aud) {
+            if (d.d_aud) d.d_aud[c] += (float)s;
+        } else if (c >= d.p.dim_aud + d.p.dim_expr) {
+            if (d.d_latent) d.d_latent[c - d.p.dim_aud - d.p.dim_expr] += (float)s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr int kMaxSplits = 256;
+constexpr int kColsumBlocks = 256;
+
+struct BwdWs {
+    float *dA[2], *dV[2], *dV0, *dRGB, *part, *cpart, *dbtmp;
+    size_t bytes;
+};
+static BwdWs carve_bwd(char* base, int64_t p_pad) {
+    BwdWs w;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* p = reinterpret_cast<float*>(base + off);
+        off += al256(floats * 4);
+        return p;
+    };
+    w.dA[0] = take((size_t)p_pad * 256);
+    w.dA[1] = take((size_t)p_pad * 256);
+    w.dV[0] = take((size_t)p_pad * 128);
+    w.dV[1] = take((size_t)p_pad * 128);
+    w.dV0 = take((size_t)p_pad * 256);
+    w.dRGB = take((size_t)p_pad * 64);
+    w.part = take((size_t)kMaxSplits * 256 * 256);
+    w.cpart = take((size_t)kColsumBlocks * 256);
+    w.dbtmp = take(1024);
+    w.bytes = off;
+    return w;
+}
+
+size_t bwd_workspace_bytes(int64_t n_points) {
+    const int64_t p_pad = (n_points + 127) / 128 * 128;
+    return carve_bwd(nullptr, p_pad).bytes;
+}
+
+static int run_nn(const float* A, int lda, const float* B, int ldb, int b_rows, const float* extra, int extra_at,
+                  float* C, int ldc, const float* mask, int ldm, int64_t M, int N, int K, hipStream_t s) {
+    NNArgs g{A, lda, B, ldb, b_rows, extra, extra_at, C, ldc, mask, ldm, K};
+    hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)(M / 128), N / 64), dim3(256), 0, s, g);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+// part[split][N][K] = A[:, :N]^T . B[:, :K] over point splits; returns the split count
+static int run_tn_partials(const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part,
+                           int* splits_out, hipStream_t s) {
+    int ntw, ktw;
+    if (N == 256 && K == 256) { ntw = 4; ktw = 4; }
+    else if (N == 256 && K == 64) { ntw = 4; ktw = 1; }
+    else if (N == 128 && K == 128) { ntw = 2; ktw = 2; }
+    else if (N == 64 && K == 128) { ntw = 1; ktw = 2; }
+    else return fail(IDN_EUNSUPPORTED, "gemm_tn: no instantiation for %d x %d", N, K);
+    const int bx = N / (64 * ntw), by = K / (64 * ktw);
+    const long chunks = P / 32;
+    int splits = kMaxSplits / (bx * by);
+    if (splits > chunks) splits = (int)chunks;
+    if (splits < 1) splits = 1;
+    const int cps = (int)((chunks + splits - 1) / splits);
+    splits = (int)((chunks + cps - 1) / cps);
+    TNArgs g{A, lda, B, ldb, part, N, K, (long)P, cps};
+    const dim3 grid(bx, by, splits), block(256);
+    if (ntw == 4 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, s, g);
+    else if (ntw == 4 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), grid, block, 0, s, g);
+    else if (ntw == 2 && ktw == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_tn_kernel<1, 2>), grid, block, 0, s, g);
+    IDN_HIP_CHECK(hipGetLastError());
+    *splits_out = splits;
+    return IDN_OK;
+}
+// out[(0..rows) x (0..cols)] (ld ldo) = sum over splits of part rows row0.. of the N x K product
+static int run_reduce(const float* part, int splits, int N, int K, int row0, float* out, int ldo, int rows, int cols,
+                      hipStream_t s) {
+    const int total = rows * cols;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part + (size_t)row0 * K,
+                       splits, N, K, out, ldo, rows, cols);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+static int run_tn(const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part, float* out,
+                  int ldo, int rows, int cols, hipStream_t s) {
+    int splits = 0;
+    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, &splits, s)) return e;
+    return run_reduce(part, splits, N, K, 0, out, ldo, rows, cols, s);
+}
+
+static int run_colsum(const float* A, int lda, int64_t P, int C, float* cpart, float* out, hipStream_t s) {
+    const long rpb = (P + kColsumBlocks - 1) / kColsumBlocks;
+    const int blocks = (int)((P + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
+    IDN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, cpart, blocks, 1, C, out, C, 1, C);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, const float* aud, const float* expr,
+                    const float* latent, const float* acts, const float* raw, const float* z, const float* rays,
+                    const float* bc, int64_t n_rays, int S, const float* g_rgb, const float* g_fg, const float* g_lw,
+                    const float* g_acc, float* d_aud, float* d_latent, void* ws_, size_t ws_bytes, hipStream_t s) {
+    const int64_t P = n_rays * S;
+    const int64_t Pp = (P + 127) / 128 * 128;
+    if (S < 2 || S > 256) return fail(IDN_EUNSUPPORTED, "pass_bwd: n_samples %d outside [2, 256]", S);
+    const BwdWs w = carve_bwd(reinterpret_cast<char*>(ws_), Pp);
+    if (!ws_ || ws_bytes < w.bytes) return fail(IDN_EWORKSPACE, "backward workspace %zu < %zu", ws_bytes, w.bytes);
+    const int C = p.dim_aud + p.dim_expr + p.dim_latent;
+    const int ld0 = IDN_PTS_CH + C, ld5 = IDN_PTS_CH + C + IDN_W, ldv = IDN_W + IDN_VIEWS_CH + p.dim_expr;
+    auto act = [&](int i) { return acts + (size_t)act_off(i) * Pp; };
+    auto a_l = [&](int l) { return act(kActA1 + l - 1); };  // post-ReLU output of pts_linears.(l-1), l = 1..8
+    auto v_l = [&](int l) { return act(kActV1 + l - 1); };  // post-ReLU output of views_linears.(l-1), l = 1..3
+
+    // d(outputs) -> d raw, written straight into the head deltas (zero elsewhere)
+    IDN_HIP_CHECK(hipMemsetAsync(w.dRGB, 0, (size_t)Pp * 64 * 4, s));
+    IDN_HIP_CHECK(hipMemsetAsync(w.dV0, 0, (size_t)Pp * 256 * 4, s));
+    {
+        CompBwdArgs a{reinterpret_cast<const float4*>(raw), z, rays, bc, g_rgb, g_fg, g_lw, g_acc,
+                      w.dRGB, 64, w.dV0 + kSigmaChannel, 256, (long)n_rays, S};
+        const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
+        switch ((S + 63) / 64) {
+            case 1: hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL(composite_bwd_kernel<2>, grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL(composite_bwd_kernel<3>, grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL(composite_bwd_kernel<4>, grid, block, 0, s, a); break;
+        }
+        IDN_HIP_CHECK(hipGetLastError());
+    }
+#define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
+    // rgb_linear: dW[3,128] = dRGB^T v3 ; db ; delta(views2 pre-act) = (dRGB . Wrgb) (.) [v3 > 0]
+    TRY(run_tn(w.dRGB, 64, 64, v_l(3), 128, 128, Pp, w.part, gr.rgb_w, 128, 3, 128, s));
+    TRY(run_colsum(w.dRGB, 64, Pp, 3, w.cpart, gr.rgb_b, s));
+    TRY(run_nn(w.dRGB, 64, p.rgb_w, 128, 3, nullptr, -1, w.dV[0], 128, v_l(3), 128, Pp, 128, 64, s));
+    // views_linears.2
+    TRY(run_tn(w.dV[0], 128, 128, v_l(2), 128, 128, Pp, w.part, gr.views_w[2], 128, 128, 128, s));
+    TRY(run_colsum(w.dV[0], 128, Pp, 128, w.cpart, gr.views_b[2], s));
+    TRY(run_nn(w.dV[0], 128, p.views_w[2], 128, 128, nullptr, -1, w.dV[1], 128, v_l(2), 128, Pp, 128, 128, s));
+    // views_linears.1 ; its input delta lands in columns 0..127 of dV0 (column 128 already holds d sigma)
+    TRY(run_tn(w.dV[1], 128, 128, v_l(1), 128, 128, Pp, w.part, gr.views_w[1], 128, 128, 128, s));
+    TRY(run_colsum(w.dV[1], 128, Pp, 128, w.cpart, gr.views_b[1], s));
+    TRY(run_nn(w.dV[1], 128, p.views_w[1], 128, 128, nullptr, -1, w.dV0, 256, v_l(1), 128, Pp, 128, 128, s));
+    // views_linears.0 (+ alpha_linear as channel 128); inputs [a8 | dirPE | expr(folded)]
+    {
+        int splits = 0;
+        TRY(run_tn_partials(w.dV0, 256, 256, a_l(8), 256, 256, Pp, w.part, &splits, s));
+        TRY(run_reduce(w.part, splits, 256, 256, 0, gr.views_w[0], ldv, 128, 256, s));
+        TRY(run_reduce(w.part, splits, 256, 256, kSigmaChannel, gr.alpha_w, 256, 1, 256, s));
+        TRY(run_tn_partials(w.dV0, 256, 256, act(kActDir), 64, 64, Pp, w.part, &splits, s));
+        TRY(run_reduce(w.part, splits, 256, 64, 0, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH, s));
+        TRY(run_colsum(w.dV0, 256, Pp, 256, w.cpart, w.dbtmp, s));
+        IDN_HIP_CHECK(hipMemcpyAsync(gr.views_b[0], w.dbtmp, 128 * 4, hipMemcpyDeviceToDevice, s));
+        IDN_HIP_CHECK(hipMemcpyAsync(gr.alpha_b, w.dbtmp + kSigmaChannel, 4, hipMemcpyDeviceToDevice, s));
+    }
+    float* cur = w.dA[0];
+    float* nxt = w.dA[1];
+    TRY(run_nn(w.dV0, 256, p.views_w[0], ldv, 128, p.alpha_w, kSigmaChannel, cur, 256, a_l(8), 256, Pp, 256, 256, s));
+    // trunk: cur = delta of pts_linears.l's pre-activation
+    for (int l = 7; l >= 1; --l) {
+        if (l == 5) {
+            TRY(run_tn(cur, 256, 256, a_l(5), 256, 256, Pp, w.part, gr.pts_w[5] + IDN_PTS_CH + C, ld5, 256, 256, s));
+            TRY(run_tn(cur, 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[5], ld5, 256, IDN_PTS_CH, s));
+        } else {
+            TRY(run_tn(cur, 256, 256, a_l(l), 256, 256, Pp, w.part, gr.pts_w[l], 256, 256, 256, s));
+        }
+        TRY(run_colsum(cur, 256, Pp, 256, w.cpart, gr.pts_b[l], s));
+        const float* B = (l == 5) ? p.pts_w[5] + IDN_PTS_CH + C : p.pts_w[l];
+        TRY(run_nn(cur, 256, B, l == 5 ? ld5 : 256, 256, nullptr, -1, nxt, 256, a_l(l), 256, Pp, 256, 256, s));
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    TRY(run_tn(cur, 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[0], ld0, 256, IDN_PTS_CH, s));
+    TRY(run_colsum(cur, 256, Pp, 256, w.cpart, gr.pts_b[0], s));
+#undef TRY
+    {
+        FoldBwdArgs f{p, aud, expr, latent, gr.pts_b[0], gr.pts_b[5], gr.views_b[0], gr.pts_w[0], gr.pts_w[5],
+                      gr.views_w[0], d_aud, d_latent};
+        const int total = IDN_W * C + (IDN_W / 2) * p.dim_expr + C;
+        if (total > 0) {
+            hipLaunchKernelGGL(fold_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, f);
+            IDN_HIP_CHECK(hipGetLastError());
+        }
+    }
+    return IDN_OK;
+}
+
+}  // namespace idn

@@ -208,6 +208,50 @@ typedef struct idn_render_args {
 size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step (NeRFs/HeadNeRF/train/audio_exp_nerf.py:534-552).  The forward of a pass is
+ * idealnerf_coarse_depths / _query_rays_train_fwd / _composite_fwd / _sample_pdf_fwd; the
+ * backward of a pass is one call.  z_samples are detached upstream (:345), so depths carry
+ * no gradient; gradients reach the network parameters and the per-frame aud / latent vectors.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Floats of the activation slab idealnerf_query_rays_train_fwd fills for n_points points
+ * (2560 columns x n_points rounded up to 128 rows; need not be initialised). */
+size_t idealnerf_train_acts_floats(int64_t n_points);
+
+/* idealnerf_query_rays_fwd that also records what the backward needs (the post-ReLU
+ * activations of all 11 hidden layers and both encodings). */
+int idealnerf_query_rays_train_fwd(const float* packed, const float* folded, int precision, const float* rays,
+                                   const float* z, int64_t n_rays, int n_samples, float* raw, float* acts,
+                                   void* stream);
+
+/* Gradient tensors, same shapes/layout as idn_facenerf_params (every entry is overwritten,
+ * including the conditioning columns). */
+typedef struct idn_facenerf_grads {
+    float* pts_w[8];
+    float* pts_b[8];
+    float* views_w[3];
+    float* views_b[3];
+    float* alpha_w;
+    float* alpha_b;
+    float* rgb_w;
+    float* rgb_b;
+} idn_facenerf_grads;
+
+size_t idealnerf_pass_bwd_workspace_bytes(int64_t n_rays, int n_samples);
+
+/*
+ * Backward of raw2outputs + run_network + FaceNeRF for one pass of n_rays x n_samples points.
+ *   g_rgb_map [n,3], g_rgb_fg [n,3], g_last_weight [n], g_acc [n]: upstream gradients of the
+ *   compositing outputs (any may be NULL = zero).
+ *   d_aud [dim_aud], d_latent [dim_latent]: ACCUMULATED (+=); may be NULL.
+ */
+int idealnerf_pass_bwd(const idn_facenerf_params* p, const idn_facenerf_grads* grads, const float* aud,
+                       const float* expr, const float* latent, const float* acts, const float* raw, const float* z,
+                       const float* rays, const float* bc_rgb, int64_t n_rays, int n_samples, const float* g_rgb_map,
+                       const float* g_rgb_fg, const float* g_last_weight, const float* g_acc, float* d_aud,
+                       float* d_latent, void* workspace, size_t workspace_bytes, void* stream);
+
 /*
  * Measurement aid (no reference counterpart): between begin and end, every launch of
  * the fused PE+MLP kernel is bracketed by HIP events on its own stream.  end()
