@@ -67,6 +67,55 @@ def cpu_baseline(syn, pc, pf, gpu_rgb_band, band_row0, n_rays=8192):
     return out, psnr
 
 
+def bench_train(args):
+    """BASELINE configs[2]: May HeadNeRF train step, N_rand=3072 (2432 uniform + 512 mouth box + 128
+    outside the face rect), fwd + bwd + Adam, single GPU.  Secondary measurement; not the headline."""
+    import idealnerf_amd
+    from idealnerf_amd import synthetic, train as T_
+    from idealnerf_amd.audio_exp_nerf import Network
+    from idealnerf_amd.helper import RenderConfig
+    import numpy as np
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    H = W = 450
+    syn = synthetic.frame(H, W, seed=0)
+    cfg = RenderConfig(perturb=1.0, chunk=8192, near=syn["near"], far=syn["far"])
+    net = Network(H, W, syn["focal"], syn["near"], syn["far"], 8192, None, 64, 128, args=cfg).to(dev).train()
+    synthetic.xavier_state_dict(net.face_nerf_coarse, 2, 300.0, 0.3)
+    synthetic.xavier_state_dict(net.face_nerf_fine, 3, 300.0, 0.3)
+    rs = np.random.RandomState(0)
+    uni = rs.choice(H * W, 2432, replace=False)
+    yy, xx = np.meshgrid(np.arange(250, 310), np.arange(175, 275), indexing="ij")
+    mouth = rs.choice((yy * W + xx).reshape(-1), 512, replace=False)
+    border = rs.choice(np.arange(0, 60 * W), 128, replace=False)
+    sel = torch.from_numpy(np.concatenate([uni, mouth, border]))
+    import oracle  # only for the pinhole ray table of the synthetic pose (host-side input generation)
+    ro, rd = oracle.camera_rays(H, W, syn["focal"], syn["c2w"])
+    batch_rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0).to(dev)
+    bg = syn["bc"].reshape(-1, 3)[sel].contiguous().to(dev)
+    tgt = torch.from_numpy(rs.uniform(0, 1, size=(len(sel), 3)).astype(np.float32)).to(dev)
+    auds = torch.from_numpy(rs.standard_normal((8, 16, 29)).astype(np.float32)).to(dev)
+    pose = torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0).to(dev)
+    latent_codes = torch.ones(8, 32, device=dev, requires_grad=True)
+    opt = T_.make_optimizer(net, latent_codes)
+    data = (batch_rays[None], tgt, bg, auds[None], torch.zeros(1, H, W, 3), pose, syn["expr"][None].to(dev), torch.tensor([3]))
+    for i in range(args.warmup):
+        T_.train_step(net, opt, data, latent_codes, i, 8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        info = T_.train_step(net, opt, data, latent_codes, args.warmup + i, 8)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    samples = len(sel) * 256 * args.steps
+    print(json.dumps({"metric": "train ray-samples/sec (N_rand=3072, 64+128, fwd+bwd+Adam)", "value": samples / dt,
+                      "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "BASELINE configs[2]: May HeadNeRF train step, N_rand=3072 mouth_rays=512 "
+                                             "dim_aud=64 dim_expr=76, perturb=1"},
+                      "algorithmic_tflops": samples * 3 * FLOP_PER_SAMPLE / dt / 1e12, "final_loss": float(info["loss"])}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,7 +123,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--workload", choices=["frame", "train"], default="frame",
+                    help="frame = BASELINE configs[1] (default, the headline metric); train = configs[2] train step")
     args = ap.parse_args()
+    if args.workload == "train":
+        return bench_train(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

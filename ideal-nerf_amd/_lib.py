@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libidealnerf.so")
+LIB_PATH = os.environ.get("IDN_LIB") or os.path.join(HERE, "libidealnerf.so")
 
 IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16 = 0, 1, 2
 RAY_FLOATS = 11

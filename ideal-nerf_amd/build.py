@@ -34,6 +34,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_diag(verbose=True):
+    """Diagnostic variant (cycle stamps in the MLP kernel): libidealnerf_diag.so.  Never loaded by
+    the package unless IDN_LIB points at it; used by tools/diag_mlp.py only."""
+    obj = os.path.join(OBJ, "diag")
+    os.makedirs(obj, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        o = os.path.join(obj, src.replace(".hip", ".o"))
+        cmd = [hipcc()] + FLAGS + ["-DIDN_DIAG", "-c", os.path.join(CSRC, src), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(o)
+    lib = os.path.join(HERE, "libidealnerf_diag.so")
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
+    return lib
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -64,4 +82,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--diag" in sys.argv:
+        print(build_diag())
+    else:
+        print(build(force="--force" in sys.argv))

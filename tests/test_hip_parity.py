@@ -576,3 +576,60 @@ def test_head_torso_gradients_match_oracle(idn, dev):
     # the audio net is reached through d aud of both pairs (torso: only the first 64 channels)
     for (name, prm), (_, ref_p) in zip(net.aud_net.named_parameters(), aud_net.named_parameters()):
         assert rel_err(prm.grad, ref_p.grad) < 2e-3, name
+
+
+def test_train_loop_adam_steps_match_oracle(idn, dev):
+    """Three iterations of the reference's loop body (audio_exp_nerf.py:530-558) through
+    Network.forward's 9-tuple: loss trajectory, PSNR, learning rate and the updated weights
+    against the CPU oracle driven by the same torch Adam."""
+    from idealnerf_amd import train as T_
+    net, syn = _train_net(idn, dev)
+    dims = oracle.facenerf_dims()
+    rs = np.random.RandomState(3)
+    n = 96
+    ro, rd = oracle.camera_rays(32, 32, syn["focal"], syn["c2w"])
+    sel = T(rs.choice(1024, size=n, replace=False))
+    batch_rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    bg = syn["bc"].reshape(-1, 3)[sel].contiguous()
+    tgt = T(rs.uniform(0, 1, size=(n, 3)).astype(np.float32))
+    auds = T(rs.standard_normal((4, 16, 29)).astype(np.float32))
+    raw_img = torch.zeros(1, 32, 32, 3)
+    pose = torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
+    latent_codes = torch.ones(4, 32, device=dev, requires_grad=True)
+    # oracle twin on the CPU
+    cpu = lambda m: {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    pc, pf = cpu(net.face_nerf_coarse), cpu(net.face_nerf_fine)
+    aud_net_o = type(net.aud_net)(64, 16)
+    aud_net_o.load_state_dict({k: v.detach().cpu() for k, v in net.aud_net.state_dict().items()})
+    lat_o = torch.ones(4, 32, requires_grad=True)
+    live = lambda p: [v for k, v in p.items() if not k.startswith("feature_linear")]
+    opt_o = torch.optim.Adam(live(pc) + live(pf) + list(aud_net_o.parameters()) + [lat_o], lr=8e-4, betas=(0.9, 0.999))
+    opt = T_.make_optimizer(net, latent_codes, lrate=8e-4)
+    rays_rec = oracle.ray_records(batch_rays[0], batch_rays[1], NEAR, FAR)
+    data = (batch_rays[None], tgt, bg, auds[None], raw_img, pose, syn["expr"][None], torch.tensor([2]))
+    for step in range(3):
+        info = T_.train_step(net, opt, data, latent_codes, step, 4, lrate=8e-4, lrate_decay=500)
+        opt_o.zero_grad()
+        aud_f = aud_net_o(auds[2:3])
+        out = oracle.render_rays(rays_rec, bg, pc, pf, aud_f, syn["expr"], lat_o[2], dims=dims)
+        loss_o, img_o = oracle.train_loss(out, tgt, lat_o[2])
+        loss_o.backward()
+        opt_o.step()
+        lr_o = 8e-4 * (0.1 ** (step / (500 * 1500)))
+        for gq in opt_o.param_groups:
+            gq["lr"] = lr_o
+        assert abs(float(info["loss"]) - float(loss_o)) < 2e-4 * abs(float(loss_o)), step
+        assert abs(float(info["psnr"]) - float(oracle.mse_to_psnr(img_o.detach()))) < 1e-2
+        assert info["lr"] == pytest.approx(lr_o)
+    for name in ("pts_linears.0.weight", "pts_linears.5.weight", "views_linears.0.weight", "alpha_linear.weight",
+                 "rgb_linear.bias"):
+        got = dict(net.face_nerf_fine.named_parameters())[name].detach().cpu()
+        # Adam's first steps move every weight by ~lr * sign(g): entries whose gradient is
+        # rounding noise around zero can land 2*lr apart, everything else must agree
+        diff = (got - pf[name].detach()).abs()
+        assert float((diff > 1e-4).float().mean()) < 0.02, name
+        assert float(diff.median()) < 1e-5, name
+        assert float(diff.max()) < 3 * 2 * 8e-4 + 1e-6, name
+    assert abs_err(latent_codes[2], lat_o[2]) < 2e-4
+    assert torch.equal(latent_codes[0].detach().cpu(), torch.ones(32))  # untouched frames keep their code
+    assert dict(net.face_nerf_fine.named_parameters())["feature_linear.weight"].grad is None
