@@ -21,7 +21,9 @@ namespace idn {
 // 32 T + (r & 3) + 8 (r >> 2) + 4 h = 8 g + 4 h + j.  Activations therefore never
 // leave registers between layers.
 //
-// Within a layer, fragments are ordered g-major then t.  K sources are concatenated in
+// Within a layer, fragments are ordered tile-major (all k-groups of n-tile 0, then tile 1,
+// ...), so output tiles finish one after the other and their ReLU / the next tile's bias load
+// ride in the MFMA shadow of the neighbouring tile.  K sources are concatenated in
 // k-groups of 8 channels (zero padded): PE(63 -> 8 groups), hidden (256 -> 32 groups),
 // direction PE (27 -> 4 groups).  The conditioning columns are not in the stream; they
 // are folded into the per-frame bias block (idealnerf_fold_conditioning).

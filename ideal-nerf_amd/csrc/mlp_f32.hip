@@ -64,38 +64,44 @@ struct Diag {};
 
 // ---------------------------------------------------------------------------
 // weight stream: global -> LDS ring
+//
+// The ring holds two 64 KiB slices.  A slice is fetched by 16 "pieces" (one
+// global_load_lds_dwordx4 per wave each = 4 KiB per piece); the pieces of slice s+1 are
+// issued one per fragment-pair step during the first half of slice s, so their address
+// arithmetic rides in MFMA shadows instead of stalling the restart after a barrier.
 // ---------------------------------------------------------------------------
+constexpr int kPieces = kSliceFrags / 4;  // 16
+
 struct WStream {
     Diag* dg;
     const char* gbase;  // stream start + this lane's 16-byte column
-    const char* gnext;  // same, for the next slice to fetch
+    const char* gnext;  // same, for the slice currently being fetched
     int next_slice;
     char* ring_wave;    // ring + wave * 1 KiB (wave-uniform LDS destination base)
 
-    // Fetch the next 64 KiB slice into ring slot SLOT: 16 x (4 waves x 1 KiB).
-    template <int SLOT>
-    __device__ __forceinline__ void issue() {
-        static_for<kSliceFrags / 4>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gnext + i * 4096),
-                                             LDS_PTR(ring_wave + SLOT * kSliceBytes + i * 4096), 16, 0, 0);
-        });
+    __device__ __forceinline__ void advance() {
         gnext += kSliceBytes;
         if (++next_slice == kNumSlices) {
             next_slice = 0;
             gnext = gbase;
         }
     }
-    // Enter the slice that lives in slot SLOT: every wave's share of it has landed
-    // (vmcnt(0) precedes the barrier) and every wave is done reading the other slot.
-    template <int SLOT>
-    __device__ __forceinline__ void enter() {
-        __syncthreads();
-        issue<SLOT ^ 1>();
+    template <int SLOT, int J>
+    __device__ __forceinline__ void issue_piece() {
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gnext + J * 4096),
+                                         LDS_PTR(ring_wave + SLOT * kSliceBytes + J * 4096), 16, 0, 0);
+        if constexpr (J == kPieces - 1) advance();
     }
-    template <int SLOT>
-    __device__ __forceinline__ void prefetch_other() {
-        issue<SLOT ^ 1>();
+    template <int SLOT, int J0>
+    __device__ __forceinline__ void issue_rest() {
+        static_for<kPieces - J0>([&](auto I) { issue_piece<SLOT, J0 + decltype(I)::value>(); });
+    }
+    // every wave's share of the slice to be read next has landed (vmcnt(0) precedes the
+    // barrier) and every wave is done reading the other slot
+    __device__ __forceinline__ void open_slice() {
+        DIAG_BEGIN(*dg);
+        __syncthreads();
+        DIAG_END(*dg, kDgBarrier);
     }
 };
 
@@ -104,14 +110,13 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 }
 
 // ---------------------------------------------------------------------------
-// A-fragment reads.  hipcc (ROCm 7.2) waits lgkmcnt(0) after a prefetching ds_read --
-// i.e. for the read it has just issued -- which exposes one LDS latency per eight MFMAs
-// (measured: SQ_WAIT_ANY 10 % of wave cycles, MFMA pipe 87 % busy).  The reads are therefore
-// issued from inline asm, which the compiler does not count, and retired by a counted wait
-// tied to the destination registers ("+v"): LDS operations return in order, so
-// lgkmcnt(1) right after issuing fragment i+1 means fragment i has landed.  Compiler-issued
-// LDS/SMEM operations in between only make these waits stricter (never weaker), and its own
-// counted waits likewise (cdna_hip_programming.md section 5.7).
+// A-fragment reads.  hipcc (ROCm 7.2) waits lgkmcnt(0) after a prefetching ds_read -- i.e.
+// for the read it has just issued.  The reads are therefore issued from inline asm, which
+// the compiler does not count, and retired by a counted wait tied to the destination
+// registers ("+v"): LDS operations return in order, so lgkmcnt(2) right after issuing pair
+// p+1 means pair p has landed.  Compiler-issued LDS/SMEM operations in between only make
+// these waits stricter (never weaker), and its own counted waits likewise
+// (cdna_hip_programming.md section 5.7).
 // ---------------------------------------------------------------------------
 struct FragReader {
     uint32_t addr0, addr1;  // LDS byte address of this lane's 16 bytes in fragment 0 / fragment 64
@@ -135,47 +140,31 @@ struct FragReader {
     }
 };
 
-template <int F>
-__device__ __forceinline__ void enter_slice_of(WStream& ws) {
-    if constexpr (((F / kSliceFrags) & 1) == 0) ws.template enter<0>();
-    else ws.template enter<1>();
-}
-// after the barrier that opens the slice of fragment F and after the first fragment reads:
-// start fetching the following slice into the other slot
-template <int F>
-__device__ __forceinline__ void prefetch_after(WStream& ws) {
-    if constexpr (((F / kSliceFrags) & 1) == 0) ws.template prefetch_other<0>();
-    else ws.template prefetch_other<1>();
-}
-
-// acc[t] += W(layer)[32t.., k-group g] . B(g)   for all g, t of one layer.
-// F0 = index of the layer's first fragment in the stream (only F0 mod ring matters for
-// addressing, so layers whose F0 agree mod kRingFrags can share one instantiation).
-// On entry fr.pref holds fragment F0 in flight unless F0 opens a slice; on exit it holds
-// fragment F0 + NT*KG in flight unless that one opens a slice.
-template <int F0, int NT, int KG, class BGet>
-__device__ __forceinline__ void run_layer(f32x16 (&acc)[NT], BGet&& bget, WStream& ws, FragReader& fr) {
-    // Fragments are consumed in pairs (2p, 2p+1): for NT >= 2 they belong to different
-    // accumulator tiles, so the eight MFMAs of a pair alternate between two independent
-    // accumulation chains (a dependent v_mfma_f32_32x32x2_f32 issued back to back costs a
-    // few cycles more than its 64-cycle issue interval).  The reads of pair p+1 are issued
-    // ahead of the MFMAs of pair p.  Slice boundaries (multiples of 64) never split a pair.
-    constexpr int N = NT * KG;
-    static_assert(N % 2 == 0 && F0 % 2 == 0, "fragments are consumed in pairs");
+// One layer: out[t] += W[32t.., :] . B  for t = 0..NT-1, tile after tile (the stream is
+// tile-major), each tile's KG k-groups consumed as KG/2 fragment pairs = 8 MFMAs per step.
+//   * the reads of pair p+1 are issued ahead of the MFMAs of pair p;
+//   * one prefetch piece of the next slice is issued per step in the first half of a slice;
+//   * side(t, s, half) is called after each group of four MFMAs: VALU / LDS work placed
+//     there issues while the matrix pipe is busy (finished tiles' ReLU, the next tile's bias).
+// F0 = index of the layer's first fragment in the stream.  On entry fr.pref* hold pair F0
+// in flight unless F0 opens a slice; on exit they hold pair F0 + NT*KG likewise.
+template <int F0, int NT, int KG, class BGet, class Side>
+__device__ __forceinline__ void run_layer(f32x16 (&out)[NT], BGet&& bget, WStream& ws, FragReader& fr, Side&& side) {
+    constexpr int STEPS = KG / 2, NP = NT * STEPS;
+    static_assert(KG % 2 == 0 && F0 % 2 == 0, "fragments are consumed in pairs");
     if constexpr (F0 % kSliceFrags == 0) {
-        DIAG_BEGIN(*ws.dg);
-        __syncthreads();  // slice published; the other slot is free
-        DIAG_END(*ws.dg, kDgBarrier);
+        ws.open_slice();
         fr.pref0 = fr.template issue<F0>();
         fr.pref1 = fr.template issue<F0 + 1>();
-        prefetch_after<F0>(ws);  // address generation + 16 glds ride under the LDS latency
     }
     f32x4 a0 = fr.pref0, a1 = fr.pref1;
-    static_for<N / 2>([&](auto PI) {
-        constexpr int i0 = 2 * decltype(PI)::value, i1 = i0 + 1;
-        constexpr int g0 = i0 / NT, t0 = i0 % NT, g1 = i1 / NT, t1 = i1 % NT;
-        constexpr int f = F0 + i0;
+    static_for<NP>([&](auto PI) {
+        constexpr int pi = decltype(PI)::value;
+        constexpr int t = pi / STEPS, s = pi % STEPS, g0 = 2 * s, g1 = g0 + 1;
+        constexpr int f = F0 + 2 * pi;
         constexpr bool next_crosses = ((f + 2) % kSliceFrags == 0);
+        constexpr int jpos = (f % kSliceFrags) / 2;   // position of this pair inside its slice
+        constexpr int slot = (f / kSliceFrags) & 1;
         f32x4 n0 = a0, n1 = a1;
         if constexpr (!next_crosses) {
             n0 = fr.template issue<f + 2>();
@@ -184,66 +173,102 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[NT], BGet&& bget, WStrea
         } else {
             FragReader::retire<0>(a0, a1);
         }
-        acc[t0] = mfma(a0.x, bget(ic<g0>{}, ic<0>{}), acc[t0]);
-        acc[t1] = mfma(a1.x, bget(ic<g1>{}, ic<0>{}), acc[t1]);
-        acc[t0] = mfma(a0.y, bget(ic<g0>{}, ic<1>{}), acc[t0]);
-        acc[t1] = mfma(a1.y, bget(ic<g1>{}, ic<1>{}), acc[t1]);
-        acc[t0] = mfma(a0.z, bget(ic<g0>{}, ic<2>{}), acc[t0]);
-        acc[t1] = mfma(a1.z, bget(ic<g1>{}, ic<2>{}), acc[t1]);
-        acc[t0] = mfma(a0.w, bget(ic<g0>{}, ic<3>{}), acc[t0]);
-        acc[t1] = mfma(a1.w, bget(ic<g1>{}, ic<3>{}), acc[t1]);
+        if constexpr (jpos < kPieces) ws.template issue_piece<slot ^ 1, jpos>();
+        out[t] = mfma(a0.x, bget(ic<g0>{}, ic<0>{}), out[t]);
+        out[t] = mfma(a0.y, bget(ic<g0>{}, ic<1>{}), out[t]);
+        out[t] = mfma(a0.z, bget(ic<g0>{}, ic<2>{}), out[t]);
+        out[t] = mfma(a0.w, bget(ic<g0>{}, ic<3>{}), out[t]);
+        side(ic<t>{}, ic<s>{}, ic<0>{});
+        out[t] = mfma(a1.x, bget(ic<g1>{}, ic<0>{}), out[t]);
+        out[t] = mfma(a1.y, bget(ic<g1>{}, ic<1>{}), out[t]);
+        out[t] = mfma(a1.z, bget(ic<g1>{}, ic<2>{}), out[t]);
+        out[t] = mfma(a1.w, bget(ic<g1>{}, ic<3>{}), out[t]);
+        side(ic<t>{}, ic<s>{}, ic<1>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (next_crosses && i0 + 2 < N) {
-            DIAG_BEGIN(*ws.dg);
-            __syncthreads();
-            DIAG_END(*ws.dg, kDgBarrier);
+        if constexpr (next_crosses && pi + 1 < NP) {
+            ws.open_slice();
             n0 = fr.template issue<f + 2>();
             n1 = fr.template issue<f + 3>();
-            prefetch_after<f + 2>(ws);
         }
         a0 = n0;
         a1 = n1;
     });
-    fr.pref0 = a0;  // pair F0+N (already in flight) when it does not open a slice
+    fr.pref0 = a0;  // pair F0 + NT*KG (already in flight) when it does not open a slice
     fr.pref1 = a1;
 }
 
-// Skip the stream forward over slices that hold only padding (end of a pass).
+// End of a pass: the pieces of the next pass's first slice that the (short) last slice did
+// not get to issue.
 template <int F_END>
 __device__ __forceinline__ void finish_pass(WStream& ws) {
-    constexpr int consumed = (F_END + kSliceFrags - 1) / kSliceFrags;
-    static_for<kNumSlices - consumed>([&](auto I) {
-        constexpr int s = consumed + decltype(I)::value;
-        if constexpr ((s & 1) == 0) ws.template enter<0>();
-        else ws.template enter<1>();
-    });
+    static_assert(F_END % kSliceFrags != 0 && (F_END + kSliceFrags - 1) / kSliceFrags == kNumSlices,
+                  "the last consumed slice must be the stream's last and partially used");
+    constexpr int jpos = (F_END % kSliceFrags) / 2;
+    constexpr int slot = (F_END / kSliceFrags) & 1;
+    if constexpr (jpos < kPieces) ws.template issue_rest<slot ^ 1, jpos>();
 }
 
+// acc[4q..4q+3] of one tile <- bias of channels 32t + 8q + 4h + 0..3
+template <int Q>
+__device__ __forceinline__ void bias_quad(f32x16& tile, const float* bias_tile_half /* bias_s + off + 32t + 4h */) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias_tile_half + 8 * Q);
+    tile[4 * Q + 0] = b.x;
+    tile[4 * Q + 1] = b.y;
+    tile[4 * Q + 2] = b.z;
+    tile[4 * Q + 3] = b.w;
+}
+__device__ __forceinline__ void bias_tile(f32x16& tile, const float* bias_tile_half) {
+    bias_quad<0>(tile, bias_tile_half);
+    bias_quad<1>(tile, bias_tile_half);
+    bias_quad<2>(tile, bias_tile_half);
+    bias_quad<3>(tile, bias_tile_half);
+}
 template <int NT>
 __device__ __forceinline__ void load_bias(f32x16 (&acc)[NT], const float* bias_half /* bias_s + off + 4h */) {
-    static_for<NT>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        static_for<4>([&](auto Q) {
-            constexpr int q = decltype(Q)::value;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bias_half + 32 * t + 8 * q);
-            acc[t][4 * q + 0] = b.x;
-            acc[t][4 * q + 1] = b.y;
-            acc[t][4 * q + 2] = b.z;
-            acc[t][4 * q + 3] = b.w;
-        });
-    });
+    static_for<NT>([&](auto T) { bias_tile(acc[decltype(T)::value], bias_half + 32 * decltype(T)::value); });
 }
 
-template <int NT>
-__device__ __forceinline__ void relu_to(f32x16 (&dst)[NT], const f32x16 (&src)[NT]) {
-    static_for<NT>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        static_for<16>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            dst[t][r] = __builtin_amdgcn_fmed3f(src[t][r], 0.0f, __builtin_inff());  // one v_med3_f32
-        });
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }  // one v_med3_f32
+// ReLU, in place, of registers [R0, R0 + CNT) of a tile (clipped to the 16 a tile has)
+template <int R0, int CNT>
+__device__ __forceinline__ void relu_regs(f32x16& tile) {
+    static_for<CNT>([&](auto R) {
+        constexpr int r = R0 + decltype(R)::value;
+        if constexpr (r < 16) tile[r] = relu1(tile[r]);
     });
 }
+template <int NT>
+__device__ __forceinline__ void relu_tiles(f32x16 (&t)[NT]) {
+    static_for<NT>([&](auto T) { relu_regs<0, 16>(t[decltype(T)::value]); });
+}
+
+// The in-shadow work of one layer.
+//   * tile t-1 (finished) is ReLU'd while tile t accumulates;
+//   * the previous layer's last tile (`deferred`, when DEFER) is ReLU'd during the first half
+//     of tile 0 -- before any k-group that reads it (it is the LAST tile of the input);
+//   * the bias of tile t+1 is loaded during the first four steps of tile t.
+// The last tile's own ReLU is left to the next layer's `deferred`.
+template <int NT, int STEPS, bool DEFER>
+struct LayerSide {
+    f32x16* out;
+    f32x16* deferred;
+    const float* bias_half;  // bias_s + layer offset + 4h
+    template <int T, int S, int H>
+    __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {
+        constexpr int C = (16 + STEPS - 1) / STEPS;          // ReLU registers per step
+        constexpr int CD = (32 + STEPS - 1) / STEPS;         // deferred tile: done by STEPS/2
+        if constexpr (H == 0) {
+            if constexpr (T > 0) relu_regs<S * C, C>(out[T - 1]);
+            if constexpr (T == 0 && DEFER) relu_regs<S * CD, CD>(*deferred);
+        } else {
+            if constexpr (T + 1 < NT && S < 4) bias_quad<S>(out[T + 1], bias_half + 32 * (T + 1));
+        }
+    }
+};
+struct NoSide {
+    template <int T, int S, int H>
+    __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {}
+};
 
 // sin / cos of 2*pi*r for |r| <= 1/8 (Taylor in r; the first dropped terms are < 2e-9).
 __device__ __forceinline__ void sincos_2pi_small(float r, float& sn, float& cs) {
@@ -367,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
     ws.gnext = ws.gbase;
     ws.next_slice = 0;
     ws.ring_wave = ring + wave * kFragBytes;
-    ws.issue<0>();
+    ws.issue_rest<0, 0>();  // slice 0 -> slot 0
 
     FragReader fr;
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
@@ -437,7 +462,6 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
                 });
             });
         }
-
         const long p0 = tile * 128 + wave * 32;  // first point of this wave
         if constexpr (SAVE) {
             if (valid) {
@@ -456,132 +480,87 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
                 });
             }
         }
-        auto save_hid = [&](const f32x16 (&t)[8], int layer /*1..8*/) {
-            if constexpr (SAVE) save_tiles<8>(t, a.acts + act_off(kActA1 + layer - 1) * a.p_pad, 256, p0, a.n_points, stage, lane);
-        };
-        auto save_hv = [&](const f32x16 (&t)[4], int layer /*1..3*/) {
-            if constexpr (SAVE) save_tiles<4>(t, a.acts + act_off(kActV1 + layer - 1) * a.p_pad, 128, p0, a.n_points, stage, lane);
-        };
-
-        auto pe_get = [&](auto G, auto J) { return pe[decltype(G)::value][decltype(J)::value]; };
-
-        f32x16 acc[8], hid[8];
-        auto hid_get = [&](auto G, auto J) {
-            constexpr int g = decltype(G)::value, j = decltype(J)::value;
-            return hid[g >> 2][(g & 3) * 4 + j];
-        };
-
         DIAG_END(dg, kDgInput);
+
+        // Two sets of eight 32x32 tiles take turns as a layer's input (B operands) and output
+        // (accumulators); a finished layer's output is ReLU'd in place and read by the next.
+        f32x16 A[8], B[8], V[5];
+        auto pe_get = [&](auto G, auto J) { return pe[decltype(G)::value][decltype(J)::value]; };
+        auto tiles_get = [](f32x16* arr) {
+            return [arr](auto G, auto J) {
+                constexpr int g = decltype(G)::value, j = decltype(J)::value;
+                return arr[g >> 2][(g & 3) * 4 + j];
+            };
+        };
+        // One layer of the trunk / colour branch.  Inference: bias of tile 0 up front, everything
+        // else in MFMA shadows (LayerSide); the last tile's ReLU is owed to the next layer.
+        // Training (SAVE): plain boundaries -- bias, MFMAs, ReLU, store the activations.
+        auto layer = [&](auto F0c, auto NTc, auto KGc, auto DEFERc, auto& out, f32x16* deferred, auto&& bget,
+                         const float* bias_l, int save_idx) {
+            constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KG = decltype(KGc)::value;
+            constexpr bool DEFER = decltype(DEFERc)::value != 0;
+            DIAG_BEGIN(dg);
+            if constexpr (SAVE) load_bias<NT>(out, bias_l);
+            else bias_tile(out[0], bias_l);
+            DIAG_END(dg, kDgBoundary);
+            if constexpr (SAVE) {
+                run_layer<F0, NT, KG>(out, bget, ws, fr, NoSide{});
+                DIAG_BEGIN(dg);
+                if (save_idx >= 0) {  // hidden layer: ReLU + record
+                    relu_tiles<NT>(out);
+                    save_tiles<NT>(out, a.acts + (long)act_off(save_idx) * a.p_pad, 32 * NT, p0, a.n_points, stage, lane);
+                }
+                DIAG_END(dg, kDgBoundary);
+            } else {
+                run_layer<F0, NT, KG>(out, bget, ws, fr, LayerSide<NT, KG / 2, DEFER>{&out[0], deferred, bias_l});
+            }
+        };
+        constexpr bool D = !SAVE;  // deferred last-tile ReLU only exists on the inference path
+
         // ---- pts_linears.0 : PE(64) -> 256
-        DIAG_BEGIN(dg);
-        load_bias<8>(acc, bias_h + bias_off(0));
-        DIAG_END(dg, kDgBoundary);
-        run_layer<layer_f0(0), 8, 8>(acc, pe_get, ws, fr);
-        DIAG_BEGIN(dg);
-        relu_to<8>(hid, acc);
-        DIAG_END(dg, kDgBoundary);
-        DIAG_BEGIN(dg);
-        save_hid(hid, 1);
-        DIAG_END(dg, kDgBoundary);
-        // ---- pts_linears.1..4 : 256 -> 256
+        layer(ic<layer_f0(0)>{}, ic<8>{}, ic<8>{}, ic<0>{}, A, nullptr, pe_get, bias_h + bias_off(0), kActA1 + 0);
+        // ---- pts_linears.1..4 : 256 -> 256   (A -> B -> A -> B -> A)
 #pragma unroll 1
-        for (int l = 1; l <= 4; ++l) {
-            DIAG_BEGIN(dg);
-            load_bias<8>(acc, bias_h + l * 256);
-            DIAG_END(dg, kDgBoundary);
-            run_layer<layer_f0(1), 8, 32>(acc, hid_get, ws, fr);
-            DIAG_BEGIN(dg);
-            relu_to<8>(hid, acc);
-            DIAG_END(dg, kDgBoundary);
-            DIAG_BEGIN(dg);
-            save_hid(hid, l + 1);
-            DIAG_END(dg, kDgBoundary);
+        for (int l = 1; l <= 3; l += 2) {
+            layer(ic<layer_f0(1)>{}, ic<8>{}, ic<32>{}, ic<D>{}, B, &A[7], tiles_get(A), bias_h + l * 256, kActA1 + l);
+            layer(ic<layer_f0(2)>{}, ic<8>{}, ic<32>{}, ic<D>{}, A, &B[7], tiles_get(B), bias_h + (l + 1) * 256, kActA1 + l + 1);
         }
         // ---- pts_linears.5 : [PE(64) | 256] -> 256   (skip connection, face_nerf.py:61-62)
-        DIAG_BEGIN(dg);
-        load_bias<8>(acc, bias_h + bias_off(5));
-        DIAG_END(dg, kDgBoundary);
-        run_layer<layer_f0(5), 8, 40>(
-            acc,
-            [&](auto G, auto J) {
-                constexpr int g = decltype(G)::value, j = decltype(J)::value;
-                if constexpr (g < 8) return pe[g][j];
-                else return hid[(g - 8) >> 2][((g - 8) & 3) * 4 + j];
-            },
-            ws, fr);
-        DIAG_BEGIN(dg);
-        relu_to<8>(hid, acc);
-        DIAG_END(dg, kDgBoundary);
-        DIAG_BEGIN(dg);
-        save_hid(hid, 6);
-        DIAG_END(dg, kDgBoundary);
-        // ---- pts_linears.6..7
-#pragma unroll 1
-        for (int l = 6; l <= 7; ++l) {
+        layer(ic<layer_f0(5)>{}, ic<8>{}, ic<40>{}, ic<D>{}, B, &A[7],
+              [&](auto G, auto J) {
+                  constexpr int g = decltype(G)::value, j = decltype(J)::value;
+                  if constexpr (g < 8) return pe[g][j];
+                  else return A[(g - 8) >> 2][((g - 8) & 3) * 4 + j];
+              },
+              bias_h + bias_off(5), kActA1 + 5);
+        // ---- pts_linears.6, .7
+        layer(ic<layer_f0(6)>{}, ic<8>{}, ic<32>{}, ic<D>{}, A, &B[7], tiles_get(B), bias_h + bias_off(6), kActA1 + 6);
+        layer(ic<layer_f0(7)>{}, ic<8>{}, ic<32>{}, ic<D>{}, B, &A[7], tiles_get(A), bias_h + bias_off(7), kActA1 + 7);
+        // ---- views_linears.0 (+ alpha_linear as channel 128) : [256 | dirPE(32)] -> 160
+        //      tiles 0..3 are hidden units (ReLU'd while the next tile accumulates), tile 4 row 0 is sigma
+        layer(ic<layer_f0(8)>{}, ic<5>{}, ic<36>{}, ic<D>{}, V, &B[7],
+              [&](auto G, auto J) {
+                  constexpr int g = decltype(G)::value, j = decltype(J)::value;
+                  if constexpr (g < 32) return B[g >> 2][(g & 3) * 4 + j];
+                  else return pd[g - 32][j];
+              },
+              bias_h + bias_off(8), -1);
+        const float sigma = V[4][0];  // channel 128 = tile 4, register 0, lane half 0
+        if constexpr (SAVE) {
             DIAG_BEGIN(dg);
-            load_bias<8>(acc, bias_h + l * 256);
-            DIAG_END(dg, kDgBoundary);
-            run_layer<layer_f0(6), 8, 32>(acc, hid_get, ws, fr);
-            DIAG_BEGIN(dg);
-            relu_to<8>(hid, acc);
-            DIAG_END(dg, kDgBoundary);
-            DIAG_BEGIN(dg);
-            save_hid(hid, l + 1);
+            f32x16(&V4)[4] = reinterpret_cast<f32x16(&)[4]>(V);
+            relu_tiles<4>(V4);
+            save_tiles<4>(V4, a.acts + (long)act_off(kActV1) * a.p_pad, 128, p0, a.n_points, stage, lane);
             DIAG_END(dg, kDgBoundary);
         }
-        // ---- views_linears.0 (+ alpha_linear as channel 128) : [256 | dirPE(32)] -> 160
-        f32x16 va[5];
-        DIAG_BEGIN(dg);
-        load_bias<5>(va, bias_h + bias_off(8));
-        DIAG_END(dg, kDgBoundary);
-        run_layer<layer_f0(8), 5, 36>(
-            va,
-            [&](auto G, auto J) {
-                constexpr int g = decltype(G)::value, j = decltype(J)::value;
-                if constexpr (g < 32) return hid[g >> 2][(g & 3) * 4 + j];
-                else return pd[g - 32][j];
-            },
-            ws, fr);
-        const float sigma = va[4][0];  // channel 128 = tile 4, register 0, lane half 0
-        f32x16 hv[4], vb[4];
-        static_for<4>([&](auto T) {
-            constexpr int t = decltype(T)::value;
-            static_for<16>([&](auto R) { hv[t][decltype(R)::value] = __builtin_amdgcn_fmed3f(va[t][decltype(R)::value], 0.0f, __builtin_inff()); });
-        });
-        DIAG_BEGIN(dg);
-        save_hv(hv, 1);
-        DIAG_END(dg, kDgBoundary);
-        auto hv_get = [&](auto G, auto J) {
-            constexpr int g = decltype(G)::value, j = decltype(J)::value;
-            return hv[g >> 2][(g & 3) * 4 + j];
-        };
-        // ---- views_linears.1, .2 : 128 -> 128
-        DIAG_BEGIN(dg);
-        load_bias<4>(vb, bias_h + bias_off(9));
-        DIAG_END(dg, kDgBoundary);
-        run_layer<layer_f0(9), 4, 16>(vb, hv_get, ws, fr);
-        DIAG_BEGIN(dg);
-        relu_to<4>(hv, vb);
-        DIAG_END(dg, kDgBoundary);
-        DIAG_BEGIN(dg);
-        save_hv(hv, 2);
-        DIAG_END(dg, kDgBoundary);
-        DIAG_BEGIN(dg);
-        load_bias<4>(vb, bias_h + bias_off(10));
-        DIAG_END(dg, kDgBoundary);
-        run_layer<layer_f0(10), 4, 16>(vb, hv_get, ws, fr);
-        DIAG_BEGIN(dg);
-        relu_to<4>(hv, vb);
-        DIAG_END(dg, kDgBoundary);
-        DIAG_BEGIN(dg);
-        save_hv(hv, 3);
-        DIAG_END(dg, kDgBoundary);
+        // ---- views_linears.1, .2 : 128 -> 128   (V -> A[0..3] -> V[0..3])
+        f32x16(&A4)[4] = reinterpret_cast<f32x16(&)[4]>(A);
+        f32x16(&V4b)[4] = reinterpret_cast<f32x16(&)[4]>(V);
+        layer(ic<layer_f0(9)>{}, ic<4>{}, ic<16>{}, ic<0>{}, A4, nullptr, tiles_get(V), bias_h + bias_off(9), kActV1 + 1);
+        layer(ic<layer_f0(10)>{}, ic<4>{}, ic<16>{}, ic<D>{}, V4b, &A[3], tiles_get(A), bias_h + bias_off(10), kActV1 + 2);
         // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile)
         f32x16 rgb[1];
-        DIAG_BEGIN(dg);
-        load_bias<1>(rgb, bias_h + bias_off(11));
-        DIAG_END(dg, kDgBoundary);
-        run_layer<layer_f0(11), 1, 16>(rgb, hv_get, ws, fr);
+        layer(ic<layer_f0(11)>{}, ic<1>{}, ic<16>{}, ic<D>{}, rgb, &V[3], tiles_get(V), bias_h + bias_off(11), -1);
         finish_pass<kUsedFrags>(ws);
 
         DIAG_BEGIN(dg);

@@ -32,7 +32,7 @@ __global__ void pack_f32_kernel(PackDesc d, float4* out) {
         while (l + 1 < kNumLayers && f >= d.L[l + 1].f0) ++l;
         const PackLayer& L = d.L[l];
         const int rel = f - L.f0;
-        const int g = rel / L.nt, t = rel - g * L.nt;
+        const int t = rel / L.kg, g = rel - t * L.kg;  // tile-major: a tile's k-groups are consecutive
         const int n = 32 * t + (lane & 31);
         const int src = g < L.kg0 ? 0 : 1;
         const int kbase = 8 * (src ? g - L.kg0 : g) + 4 * (lane >> 5);

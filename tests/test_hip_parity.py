@@ -403,7 +403,44 @@ def test_full_size_band_properties(idn, dev):
 
 
 # --------------------------------------------------------------------------- a12: training step
+def grad_err(got, ref, scale_ref=None):
+    """max |got - ref| relative to the largest reference entry of the layer (for a bias: of its
+    weight gradient too, so a single-element gradient that cancels to ~0 is not divided by ~0)."""
+    g = got.detach().cpu().double()
+    r = ref.detach().cpu().double()
+    scale = float(r.abs().max())
+    if scale_ref is not None:
+        scale = max(scale, float(scale_ref.detach().cpu().abs().max()))
+    return float((g - r).abs().max()) / max(scale, 1e-30)
+
+
+def l2_err(got, ref):
+    g = got.detach().cpu().double()
+    r = ref.detach().cpu().double()
+    return float((g - r).norm() / r.norm().clamp_min(1e-30))
+
+
+# End-to-end gradients against CPU autograd are compared by relative L2 plus a loose max bound:
+# a hidden unit whose pre-activation is within rounding of zero gets a different ReLU mask on
+# MFMA than on the CPU BLAS (and a flipped importance index moves a fine sample), which moves
+# single rows of single tensors at the 1e-3..1e-2 level when only a few dozen rays carry the
+# gradient.  The arithmetic itself is pinned by test_backward_kernels_vs_fp64_on_saved_activations
+# (same activations, same masks: 1e-6).
+GRAD_L2_COARSE, GRAD_L2_FINE, GRAD_MAX = 2e-3, 1e-2, 5e-2
+
+
+def check_grads(named_params, ref, fine, ctx=""):
+    for name, prm in named_params:
+        if name.startswith("feature_linear"):
+            continue
+        r = ref[name].grad
+        w_ref = ref[name.replace(".bias", ".weight")].grad
+        assert l2_err(prm.grad, r) < (GRAD_L2_FINE if fine else GRAD_L2_COARSE) or grad_err(prm.grad, r, w_ref) < 1e-5, (ctx, name)
+        assert grad_err(prm.grad, r, w_ref) < GRAD_MAX, (ctx, name)
+
+
 def _train_net(idn, dev, n_importance=128):
+    torch.manual_seed(1234)  # the audio nets are torch-initialised: keep every process on the same instance
     from idealnerf_amd.audio_exp_nerf import Network
     from idealnerf_amd.helper import RenderConfig
     dims = oracle.facenerf_dims()
@@ -479,24 +516,15 @@ def test_train_step_matches_oracle_autograd_ragged(idn, dev):
         loss = loss + 10 * (torch.norm(lat) * 0.0005)
         loss.backward()
         assert abs(float(loss) - float(loss_o)) < 1e-5 * abs(float(loss_o))
-        assert rel_err(aud.grad, aud_o.grad) < 2e-3 and rel_err(lat.grad, lat_o.grad) < 2e-3
-        for name, ref in pc.items():
-            if name.startswith("feature_linear"):
-                continue
-            got = dict(net.face_nerf_coarse.named_parameters())[name].grad
-            assert rel_err(got, ref.grad) < 2e-3, (n_rays, name)
+        assert l2_err(aud.grad, aud_o.grad) < GRAD_L2_FINE and l2_err(lat.grad, lat_o.grad) < GRAD_L2_FINE
+        check_grads(net.face_nerf_coarse.named_parameters(), pc, False, n_rays)
         if ni:
-            for name, ref in pf.items():
-                if name.startswith("feature_linear"):
-                    continue
-                got = dict(net.face_nerf_fine.named_parameters())[name].grad
-                # the fine net sees the sampled depths: with a few dozen rays one flipped
-                # importance index (inherent, see CDF_TOL) shows at the 1e-3 level
-                assert rel_err(got, ref.grad) < 1e-2, (n_rays, name)
+            check_grads(net.face_nerf_fine.named_parameters(), pf, True, n_rays)
 
 
 # --------------------------------------------------------------------------- a11: head + torso composite
 def _torso_setup(idn, dev, n=48):
+    torch.manual_seed(4321)  # the audio net is torch-initialised: same instance in every process
     from idealnerf_amd.train_torso import Network
     from idealnerf_amd.helper import RenderConfig
     rs = np.random.RandomState(5)
@@ -507,8 +535,11 @@ def _torso_setup(idn, dev, n=48):
     dt = oracle.facenerf_dims(dim_aud=106, dim_expr=0, dim_latent=0)
     P = dict(hc=scale_sigma(oracle.xavier_facenerf_params(21, dh), 100.0, 0.2),
              hf=scale_sigma(oracle.xavier_facenerf_params(22, dh), 100.0, 0.2),
-             tc=scale_sigma(oracle.xavier_facenerf_params(23, dt), 100.0, 0.2),
-             tf=scale_sigma(oracle.xavier_facenerf_params(24, dt), 100.0, 0.2))
+             # semi-transparent torso: the head reaches the pixel through last_weight_torso, which must be
+             # O(0.1..1) for the head gradients to be meaningful (an opaque torso leaves ~1e-9 factors whose
+             # fp32 relative accuracy is ~1e-2 on any implementation)
+             tc=scale_sigma(oracle.xavier_facenerf_params(23, dt), 4.0, -0.2),
+             tf=scale_sigma(oracle.xavier_facenerf_params(24, dt), 4.0, -0.2))
     net.face_nerf_coarse.load_state_dict(P["hc"]); net.face_nerf_fine.load_state_dict(P["hf"])
     net.torso_coarse_nerf.load_state_dict(P["tc"]); net.torso_fine_nerf.load_state_dict(P["tf"])
     pose = torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
@@ -568,14 +599,10 @@ def test_head_torso_gradients_match_oracle(idn, dev):
     assert abs(float(loss) - float(loss_o)) < 1e-5 * abs(float(loss_o))
     pairs = (("hc", net.face_nerf_coarse), ("tc", net.torso_coarse_nerf), ("hf", net.face_nerf_fine), ("tf", net.torso_fine_nerf))
     for tag, m in pairs:
-        tol = 2e-3 if tag.endswith("c") else 1e-2  # fine nets see the sampled depths (see the ragged train test)
-        for name, prm in m.named_parameters():
-            if name.startswith("feature_linear"):
-                continue
-            assert rel_err(prm.grad, P[tag][name].grad) < tol, (tag, name)
+        check_grads(m.named_parameters(), P[tag], tag.endswith("f"), tag)
     # the audio net is reached through d aud of both pairs (torso: only the first 64 channels)
     for (name, prm), (_, ref_p) in zip(net.aud_net.named_parameters(), aud_net.named_parameters()):
-        assert rel_err(prm.grad, ref_p.grad) < 2e-3, name
+        assert l2_err(prm.grad, ref_p.grad) < GRAD_L2_FINE, name
 
 
 def test_train_loop_adam_steps_match_oracle(idn, dev):
@@ -633,3 +660,66 @@ def test_train_loop_adam_steps_match_oracle(idn, dev):
     assert abs_err(latent_codes[2], lat_o[2]) < 2e-4
     assert torch.equal(latent_codes[0].detach().cpu(), torch.ones(32))  # untouched frames keep their code
     assert dict(net.face_nerf_fine.named_parameters())["feature_linear.weight"].grad is None
+
+
+def test_backward_kernels_vs_fp64_on_saved_activations(idn, dev):
+    """The arithmetic of the backward pass (compositing backward, delta/dW GEMMs, bias sums,
+    conditioning fold) against an fp64 torch backprop that uses the SAME saved activations, hence
+    the same ReLU masks: every gradient tensor, including the folded conditioning columns."""
+    from idealnerf_amd import autograd as ag
+    from idealnerf_amd.helper import linspace01
+    net, syn, P, dims, d = _torso_setup(idn, dev)
+    for coarse_net, S in ((net.face_nerf_coarse, 64), (net.face_nerf_fine, 192)):
+        with torch.no_grad():
+            aud = net.aud_net(d["auds"][1:2].to(dev)).contiguous()
+        expr, lat = d["expr"].to(dev), d["latent"].to(dev)
+        rec = oracle.ray_records(d["batch_rays"][0], d["batch_rays"][1], NEAR, FAR).to(dev)
+        bc = d["bg"].to(dev).contiguous()
+        z = idn.ops.coarse_depths(rec, linspace01(S, dev))
+        folded = coarse_net.folded_bias(aud, expr, lat)
+        raw, acts = ag._train_query(coarse_net, folded, rec, z)
+        n = rec.shape[0]
+        Pn = n * S
+        Pp = (Pn + 127) // 128 * 128
+        rs = np.random.RandomState(S)
+        g_rgb = T(rs.standard_normal((n, 3)).astype(np.float32) * 0.01).to(dev)
+        g_lw = T(rs.standard_normal(n).astype(np.float32) * 0.01).to(dev)
+        d_aud, d_lat = torch.zeros_like(aud), torch.zeros_like(lat)
+        grads = ag._pass_bwd(coarse_net, aud, expr, lat, acts, raw, z, rec, bc, g_rgb, None, g_lw, None, d_aud, d_lat)
+        mat = lambda o, w: acts[o * Pp:(o + w) * Pp].view(Pp, w)[:Pn].double()
+        x0, dirs = mat(0, 64), mat(64, 64)
+        a = [mat(128 + 256 * i, 256) for i in range(8)]
+        v = [mat(128 + 2048 + 128 * i, 128) for i in range(3)]
+        raw64 = raw.double().cpu().requires_grad_(True)
+        comp = oracle.composite(raw64, z.double().cpu(), rec[:, 3:6].double().cpu(), bc.double().cpu())
+        ((comp[0] * g_rgb.double().cpu()).sum() + (comp[3][:, -1] * g_lw.double().cpu()).sum()).backward()
+        d_raw = raw64.grad.to(dev).view(Pn, 4)
+        sd = {k: p.detach().double() for k, p in coarse_net.named_parameters()}
+        C = 64 + 79 + 32
+        cond = torch.cat([aud.double(), expr.double() / 3, lat.double()])
+        G = {}
+        d_rgb, d_sig = d_raw[:, :3], d_raw[:, 3:4]
+        G["rgb_linear.weight"], G["rgb_linear.bias"] = d_rgb.t() @ v[2], d_rgb.sum(0)
+        dl = (d_rgb @ sd["rgb_linear.weight"]) * (v[2] > 0)
+        for i in (2, 1):
+            G[f"views_linears.{i}.weight"], G[f"views_linears.{i}.bias"] = dl.t() @ v[i - 1], dl.sum(0)
+            dl = (dl @ sd[f"views_linears.{i}.weight"]) * (v[i - 1] > 0)
+        inp_v0 = torch.cat([a[7], dirs[:, :27], (expr.double() / 3)[None].expand(Pn, -1)], 1)
+        G["views_linears.0.weight"], G["views_linears.0.bias"] = dl.t() @ inp_v0, dl.sum(0)
+        G["alpha_linear.weight"], G["alpha_linear.bias"] = d_sig.t() @ a[7], d_sig.sum(0)
+        dh = (dl @ sd["views_linears.0.weight"][:, :256] + d_sig @ sd["alpha_linear.weight"]) * (a[7] > 0)
+        d_cond = torch.zeros(C, dtype=torch.float64, device=dev)
+        for l in range(7, 0, -1):
+            inp = a[l - 1] if l != 5 else torch.cat([x0[:, :63], cond[None].expand(Pn, -1), a[4]], 1)
+            G[f"pts_linears.{l}.weight"], G[f"pts_linears.{l}.bias"] = dh.t() @ inp, dh.sum(0)
+            W = sd[f"pts_linears.{l}.weight"]
+            if l == 5:
+                d_cond += (dh @ W[:, 63:63 + C]).sum(0)
+                W = W[:, 63 + C:]
+            dh = (dh @ W) * (a[l - 1] > 0)
+        inp0 = torch.cat([x0[:, :63], cond[None].expand(Pn, -1)], 1)
+        G["pts_linears.0.weight"], G["pts_linears.0.bias"] = dh.t() @ inp0, dh.sum(0)
+        d_cond += (dh @ sd["pts_linears.0.weight"][:, 63:]).sum(0)
+        for k in G:
+            assert rel_err(grads[k], G[k]) < 5e-6, (S, k)
+        assert rel_err(d_aud, d_cond[:64]) < 5e-6 and rel_err(d_lat, d_cond[64 + 79:]) < 5e-6
