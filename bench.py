@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 1_114_368      # algorithmic, SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6   # dense bf16 MFMA: 16x the fp32 rate (1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
 
 
 def host_cpu_share():
@@ -123,6 +124,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default=os.environ.get("IDN_PRECISION", "f32"),
+                    help="arithmetic of the MLP contraction (both meet the 1e-4 RGB parity bar)")
     ap.add_argument("--workload", choices=["frame", "train"], default="frame",
                     help="frame = BASELINE configs[1] (default, the headline metric); train = configs[2] train step")
     args = ap.parse_args()
@@ -156,14 +159,16 @@ def main():
     r0, r1 = parallel.row_band(H, rank, world)
     bc = syn["bc"][r0:r1].reshape(-1, 3).contiguous().to(dev)
     t_vals, u = linspace01(S, dev), linspace01(Ni, dev)
+    coarse.precision = fine.precision = args.precision
     pk_c, pk_f = coarse.packed_weights(), fine.packed_weights()
+    prec = coarse.prec_code
 
     def step():
         # per frame: pose -> rays, conditioning -> biases, then the per-ray path, then the tile exchange
         rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0, device=dev)
         fc = coarse.folded_bias(aud, expr, latent)
         ff = fine.folded_bias(aud, expr, latent)
-        out = ops.render_rays_fwd(rays, bc, pk_c, fc, pk_f, ff, t_vals, u, Ni)
+        out = ops.render_rays_fwd(rays, bc, pk_c, fc, pk_f, ff, t_vals, u, Ni, precision=prec)
         tile = out["rgb_map"].reshape(r1 - r0, W, 3)
         return parallel.gather_rows(tile, H), tile
 
@@ -205,18 +210,24 @@ def main():
         samples = H * W * (S + S + Ni) * args.steps
         value = samples / dt
         ach = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12 if k_ms.value > 0 else None
+        # a bf16x3 kernel issues three bf16 MFMAs per algorithmic product: it is priced against peak / 3
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+        kname = ("idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)" if args.precision == "f32" else
+                 "idn::mlp_bf16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 bf16 MFMAs per product)")
+        if args.precision != "f32":
+            traffic = None
         res = {
             "metric": "ray-samples/sec (64+128 pts, 512x512), whole job", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3 (fp32 in/out, fp32 accumulate)", "data": "synthetic",
             "per_gpu": value / world, "rays_per_s": value / (S + S + Ni),
             "config": {"workload": f"BASELINE configs[1]: May HeadNeRF {H}x{W} full-frame render, N_sample=64 "
                                    "N_importance=128, dim_aud=64 dim_expr=76 latent=32, perturb=0",
                        "rays_per_step": H * W, "samples_per_ray": S + S + Ni,
                        "partition": f"{world} row band(s) + RCCL all_gather of rgb tiles" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)",
-                         "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": (ach / peak) if ach else None, "traffic": traffic,
                          "launches": k_n.value, "avg_launch_ms": (k_ms.value / k_n.value) if k_n.value else None,
                          "flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": (k_pts.value / k_n.value) if k_n.value else None,
                          "kernel_time_share": (k_ms.value * 1e-3) / dt if dt > 0 else None},

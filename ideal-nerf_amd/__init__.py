@@ -13,4 +13,4 @@ at the repository root makes it importable).  Layout mirrors the reference:
 __version__ = "0.1.0"
 
 from . import _lib, ops  # noqa: F401
-from .models.face_nerf import FaceNeRF  # noqa: F401
+from .models.face_nerf import FaceNeRF, set_default_precision  # noqa: F401

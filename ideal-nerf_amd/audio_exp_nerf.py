@@ -122,8 +122,9 @@ class Network(nn.Module):
             fc = coarse.folded_bias(aud_para, expr, latent_code)
             ff = fine.folded_bias(aud_para, expr, latent_code) if Ni > 0 else None
             out = ops.render_rays_fwd(rays, bc_rgb, coarse.packed_weights(), fc,
-                                      fine.packed_weights() if Ni > 0 else None, ff,
-                                      linspace01(S, dev), u, Ni, t_rand=t_rand, with_fg=with_fg, taps=taps or retraw)
+                                      fine.packed_weights(coarse.precision) if Ni > 0 else None, ff,
+                                      linspace01(S, dev), u, Ni, t_rand=t_rand, with_fg=with_fg, taps=taps or retraw,
+                                      precision=coarse.prec_code)
         ret = {'rgb_map': out['rgb_map'], 'disp_map': out['disp_map'], 'acc_map': out['acc_map']}
         if with_fg:
             ret['rgb_map_fg'] = out['rgb_fg']
@@ -171,7 +172,7 @@ class Network(nn.Module):
         with torch.no_grad():
             folded = nerf_model.folded_bias(aud, expr, latent_code)
             return ops.query_points_fwd(nerf_model.packed_weights(), folded, inputs.to(torch.float32).contiguous(),
-                                        viewdirs.to(torch.float32).contiguous())
+                                        viewdirs.to(torch.float32).contiguous(), nerf_model.prec_code)
 
     # ---- render_dynamic_face: audio_exp_nerf.py:389-439 ------------------------------
     def render_dynamic_face(self, H, W, focal, expr, poses, latent_code, render_poses=None, chunk=1024 * 32,

@@ -50,7 +50,7 @@ def _train_query(net, folded, rays, z):
     n, S = z.shape
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=z.device)
     acts = torch.empty(lib.idealnerf_train_acts_floats(n * S), dtype=torch.float32, device=z.device)
-    check(lib.idealnerf_query_rays_train_fwd(net.packed_weights().data_ptr(), folded.data_ptr(), IDN_PREC_F32,
+    check(lib.idealnerf_query_rays_train_fwd(net.packed_weights("f32").data_ptr(), folded.data_ptr(), IDN_PREC_F32,
                                              rays.data_ptr(), z.data_ptr(), n, S, raw.data_ptr(), acts.data_ptr(),
                                              torch.cuda.current_stream().cuda_stream))
     return raw, acts

@@ -16,8 +16,20 @@ int fail(int code, const char* fmt, ...) {
 }
 
 static int check_precision(int precision) {
+    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3) return IDN_OK;
+    return fail(IDN_EUNSUPPORTED, "precision %d is not built into this library (IDN_PREC_F32, IDN_PREC_BF16X3)", precision);
+}
+static int check_precision_f32(int precision) {
     if (precision == IDN_PREC_F32) return IDN_OK;
-    return fail(IDN_EUNSUPPORTED, "precision %d is not built into this library (only IDN_PREC_F32)", precision);
+    return fail(IDN_EUNSUPPORTED, "the training path is built for IDN_PREC_F32 only (got %d)", precision);
+}
+
+int launch_mlp(int precision, const float* packed, const float* folded, const float* x, const float* rays,
+               const float* z, const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw,
+               hipStream_t s) {
+    if (precision == IDN_PREC_BF16X3)
+        return launch_mlp_bf16x3(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
+    return launch_mlp_f32(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
 }
 
 static int check_params(const idn_facenerf_params* p) {
@@ -66,7 +78,8 @@ int idealnerf_version(void) { return 1; }
 const char* idealnerf_last_error(void) { return g_err; }
 
 size_t idealnerf_packed_weight_floats(int precision) {
-    return precision == IDN_PREC_F32 ? (size_t)kStreamFrags * kFragFloats : 0;
+    // both built streams spend 4 bytes per weight (fp32, or bf16 hi + bf16 lo)
+    return (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3) ? (size_t)kStreamFrags * kFragFloats : 0;
 }
 size_t idealnerf_folded_bias_floats(void) { return kBiasFloats; }
 
@@ -74,6 +87,7 @@ int idealnerf_pack_weights(const idn_facenerf_params* p, int precision, float* p
     if (int e = check_params(p)) return e;
     if (int e = check_precision(precision)) return e;
     if (!packed) return fail(IDN_EINVAL, "packed is NULL");
+    if (precision == IDN_PREC_BF16X3) return launch_pack_bf16x3(*p, packed, (hipStream_t)stream);
     return launch_pack_f32(*p, packed, (hipStream_t)stream);
 }
 
@@ -94,7 +108,7 @@ int idealnerf_facenerf_fwd(const float* packed, const float* folded, int precisi
     if (n < 0) return fail(IDN_EINVAL, "n < 0");
     if (n == 0) return IDN_OK;
     if (!packed || !folded || !x || !out) return fail(IDN_EINVAL, "NULL pointer");
-    return launch_mlp_f32(packed, folded, x, nullptr, nullptr, nullptr, nullptr, n, 1, out, (hipStream_t)stream);
+    return launch_mlp(precision, packed, folded, x, nullptr, nullptr, nullptr, nullptr, n, 1, out, (hipStream_t)stream);
 }
 
 int idealnerf_query_rays_fwd(const float* packed, const float* folded, int precision, const float* rays,
@@ -103,8 +117,8 @@ int idealnerf_query_rays_fwd(const float* packed, const float* folded, int preci
     if (n_rays < 0 || n_samples < 1) return fail(IDN_EINVAL, "bad sizes n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
     if (n_rays == 0) return IDN_OK;
     if (!packed || !folded || !rays || !z || !raw) return fail(IDN_EINVAL, "NULL pointer");
-    return launch_mlp_f32(packed, folded, nullptr, rays, z, nullptr, nullptr, n_rays * n_samples, n_samples, raw,
-                          (hipStream_t)stream);
+    return launch_mlp(precision, packed, folded, nullptr, rays, z, nullptr, nullptr, n_rays * n_samples, n_samples, raw,
+                      (hipStream_t)stream);
 }
 
 int idealnerf_query_points_fwd(const float* packed, const float* folded, int precision, const float* pts,
@@ -113,8 +127,8 @@ int idealnerf_query_points_fwd(const float* packed, const float* folded, int pre
     if (n_rays < 0 || n_samples < 1) return fail(IDN_EINVAL, "bad sizes n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
     if (n_rays == 0) return IDN_OK;
     if (!packed || !folded || !pts || !viewdirs || !raw) return fail(IDN_EINVAL, "NULL pointer");
-    return launch_mlp_f32(packed, folded, nullptr, nullptr, nullptr, pts, viewdirs, n_rays * n_samples, n_samples, raw,
-                          (hipStream_t)stream);
+    return launch_mlp(precision, packed, folded, nullptr, nullptr, nullptr, pts, viewdirs, n_rays * n_samples, n_samples,
+                      raw, (hipStream_t)stream);
 }
 
 int idealnerf_frame_rays(const float* c2w, int H, int W, float focal, float cx, float cy, float near_, float far_,
@@ -169,7 +183,7 @@ size_t idealnerf_train_acts_floats(int64_t n_points) {
 int idealnerf_query_rays_train_fwd(const float* packed, const float* folded, int precision, const float* rays,
                                    const float* z, int64_t n_rays, int n_samples, float* raw, float* acts,
                                    void* stream) {
-    if (int e = check_precision(precision)) return e;
+    if (int e = check_precision_f32(precision)) return e;
     if (n_rays < 0 || n_samples < 1) return fail(IDN_EINVAL, "bad sizes");
     if (n_rays == 0) return IDN_OK;
     if (!packed || !folded || !rays || !z || !raw || !acts) return fail(IDN_EINVAL, "NULL pointer");
@@ -296,7 +310,7 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
         const float* rays = a->rays + r0 * IDN_RAY_FLOATS;
         const float* bc = a->bc_rgb + r0 * 3;
         if (int e = launch_coarse_depths(rays, a->t_vals, off(a->t_rand, r0 * S), c, S, w.z_c, st)) return e;
-        if (int e = launch_mlp_f32(a->packed_coarse, a->folded_coarse, nullptr, rays, w.z_c, nullptr, nullptr, c * S, S, w.raw_c, st)) return e;
+        if (int e = launch_mlp(a->precision, a->packed_coarse, a->folded_coarse, nullptr, rays, w.z_c, nullptr, nullptr, c * S, S, w.raw_c, st)) return e;
         idn_composite_out co = {};
         const bool fine = Ni > 0;
         co.rgb_map = off(fine ? a->rgb0 : a->rgb_map, r0 * 3);
@@ -317,7 +331,7 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
                                       off(a->tap_z_samples, r0 * Ni), off(a->tap_inds, r0 * Ni),
                                       off(a->tap_cdf, r0 * (S - 1)), w.z_f, off(a->z_std, r0), st))
             return e;
-        if (int e = launch_mlp_f32(a->packed_fine, a->folded_fine, nullptr, rays, w.z_f, nullptr, nullptr, c * Sf, Sf, w.raw_f, st)) return e;
+        if (int e = launch_mlp(a->precision, a->packed_fine, a->folded_fine, nullptr, rays, w.z_f, nullptr, nullptr, c * Sf, Sf, w.raw_f, st)) return e;
         idn_composite_out fo = {};
         fo.rgb_map = off(a->rgb_map, r0 * 3);
         fo.disp_map = off(a->disp_map, r0);

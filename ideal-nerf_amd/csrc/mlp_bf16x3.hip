@@ -1,0 +1,306 @@
+// Fused positional-encoding + FaceNeRF MLP forward, bf16x3 arithmetic (gfx950).
+//
+// Same computation, stream geometry and tile-major layer driver as mlp_f32.hip, but each
+// fp32 product a*b is evaluated on the bf16 matrix pipe as
+//      a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,      x_hi = bf16(x), x_lo = bf16(x - x_hi)
+// with fp32 accumulation (v_mfma_f32_32x32x16_bf16, 3 per 16 channels): ~2^-16 relative
+// error per product, ~1.5e-5 on the network output (hard part 3) -- inside
+// the 1e-4 RGB budget -- at 16/3 = 5.3x the fp32-MFMA rate, and on a pipe that does not share
+// the vector ALUs (DESIGN.md "What bounds the fp32 kernel").
+//
+// A fragment pair (2p, 2p+1) of the stream is the hi and the lo half of one 16-channel
+// k-step: 8 bf16 per lane each.  An accumulator tile (32 channels x 32 points, fp32) is
+// ReLU'd and split into two k-steps of packed hi / lo B operands in registers; element j of
+// k-step s in lane half h is register 8s+j = channel 16s + (j&3) + 8(j>>2) + 4h, which is how
+// pack_bf16x3_kernel orders the weights.
+#include "mlp_common.h"
+
+namespace idn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// (lo half, hi half) = (bf16(x0), bf16(x1)), round to nearest even
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+    return r;
+}
+// one packed word of the hi part and of the lo part from two fp32 values
+__device__ __forceinline__ void split2(float x0, float x1, float& hi_w, float& lo_w) {
+    const unsigned h = cvt_pk_bf16(x0, x1);
+    const float f0 = __uint_as_float(h << 16), f1 = __uint_as_float(h & 0xffff0000u);
+    hi_w = __uint_as_float(h);
+    lo_w = __uint_as_float(cvt_pk_bf16(x0 - f0, x1 - f1));
+}
+
+// Packed activations of one 32-channel tile: two k-steps, hi and lo.
+struct BTile {
+    f32x4 hi[2], lo[2];
+};
+// word W (0..7) of a tile: registers 2W, 2W+1 of the accumulator -> word W&3 of k-step W>>2
+template <int W, bool RELU>
+__device__ __forceinline__ void convert_word(const f32x16& acc, BTile& out) {
+    float x0 = acc[2 * W], x1 = acc[2 * W + 1];
+    if constexpr (RELU) {
+        x0 = relu1(x0);
+        x1 = relu1(x1);
+    }
+    float hw, lw;
+    split2(x0, x1, hw, lw);
+    out.hi[W >> 2][W & 3] = hw;
+    out.lo[W >> 2][W & 3] = lw;
+}
+template <int W0, int CNT, bool RELU>
+__device__ __forceinline__ void convert_words(const f32x16& acc, BTile& out) {
+    static_for<CNT>([&](auto I) {
+        constexpr int w = W0 + decltype(I)::value;
+        if constexpr (w < 8) convert_word<w, RELU>(acc, out);
+    });
+}
+
+// In-shadow work of one layer (bf16 MFMAs leave the vector ALUs free):
+//   * `pend` (the previous tile's finished accumulator) is ReLU'd + split into out[t-1];
+//     for tile 0 with DEFER it is the previous LAYER's last tile, written into `deferred`;
+//   * the bias of tile t+1 is loaded into the idle accumulator.
+template <int NT, int STEPS, bool DEFER>
+struct SideBf {
+    BTile* out;
+    BTile* deferred;
+    f32x16* pend;
+    f32x16* acc;             // acc[2]: tile t accumulates in acc[t & 1]
+    const float* bias_half;  // bias_s + layer offset + 4h
+    template <int T, int S, int H>
+    __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {
+        constexpr int C = (8 + STEPS - 1) / STEPS;       // words per step
+        constexpr int CD = (16 + STEPS - 1) / STEPS;     // deferred tile: done by STEPS/2
+        if constexpr (H == 0) {
+            if constexpr (T > 0) convert_words<S * C, C, true>(*pend, out[T - 1]);
+            if constexpr (T == 0 && DEFER) convert_words<S * CD, CD, true>(*pend, *deferred);
+        } else {
+            if constexpr (T + 1 < NT && S < 4) bias_quad<S>(acc[(T + 1) & 1], bias_half + 32 * (T + 1));
+        }
+    }
+};
+
+// One layer, tile-major: for each n-tile t, KS k-steps of (A_hi, A_lo) x (B_hi, B_lo).
+// On exit `pend` holds the last tile's accumulator (to be converted by the caller / next layer).
+template <int F0, int NT, int KS, bool DEFER, class BHi, class BLo>
+__device__ __forceinline__ void run_layer_bf(BTile* out, BTile* deferred, f32x16& pend, f32x16 (&acc)[2],
+                                             const float* bias_half, BHi&& bhi, BLo&& blo, WStream& ws, FragReader& fr) {
+    constexpr int NP = NT * KS;
+    static_assert(F0 % 2 == 0, "fragments are consumed in (hi, lo) pairs");
+    bias_tile(acc[0], bias_half);
+    const SideBf<NT, KS, DEFER> side{out, deferred, &pend, &acc[0], bias_half};
+    if constexpr (F0 % kSliceFrags == 0) {
+        ws.open_slice();
+        fr.pref0 = fr.template issue<F0>();
+        fr.pref1 = fr.template issue<F0 + 1>();
+    }
+    f32x4 a0 = fr.pref0, a1 = fr.pref1;
+    static_for<NP>([&](auto PI) {
+        constexpr int pi = decltype(PI)::value;
+        constexpr int t = pi / KS, s = pi % KS;
+        constexpr int f = F0 + 2 * pi;
+        constexpr bool next_crosses = ((f + 2) % kSliceFrags == 0);
+        constexpr int jpos = (f % kSliceFrags) / 2;
+        constexpr int slot = (f / kSliceFrags) & 1;
+        f32x4 n0 = a0, n1 = a1;
+        if constexpr (!next_crosses) {
+            n0 = fr.template issue<f + 2>();
+            n1 = fr.template issue<f + 3>();
+            FragReader::retire<2>(a0, a1);
+        } else {
+            FragReader::retire<0>(a0, a1);
+        }
+        if constexpr (jpos < kPieces) ws.template issue_piece<slot ^ 1, jpos>();
+        const f32x4 bh = bhi(ic<s>{}), bl = blo(ic<s>{});
+        acc[t & 1] = mfma_bf(a0, bh, acc[t & 1]);   // hi * hi
+        side(ic<t>{}, ic<s>{}, ic<0>{});
+        acc[t & 1] = mfma_bf(a0, bl, acc[t & 1]);   // hi * lo
+        side(ic<t>{}, ic<s>{}, ic<1>{});
+        acc[t & 1] = mfma_bf(a1, bh, acc[t & 1]);   // lo * hi
+        if constexpr (s == KS - 1) pend = acc[t & 1];  // tile t done: hand it to the converter
+        if constexpr (next_crosses && pi + 1 < NP) {
+            ws.open_slice();
+            n0 = fr.template issue<f + 2>();
+            n1 = fr.template issue<f + 3>();
+        }
+        a0 = n0;
+        a1 = n1;
+    });
+    fr.pref0 = a0;
+    fr.pref1 = a1;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    float* bias_s = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < kBiasFloats; i += 256) bias_s[i] = a.bias[i];
+
+    Diag dg;
+    WStream ws;
+    ws.dg = &dg;
+    ws.gbase = reinterpret_cast<const char*>(a.wstream) + tid * 16;
+    ws.gnext = ws.gbase;
+    ws.next_slice = 0;
+    ws.ring_wave = ring + wave * kFragBytes;
+    ws.issue_rest<0, 0>();
+
+    FragReader fr;
+    fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
+    fr.addr1 = fr.addr0 + 64 * kFragBytes;
+    const float* bias_h = bias_s + 4 * h;
+    const long ntiles = (a.n_points + 127) >> 7;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long P = tile * 128 + wave * 32 + m;
+        const bool valid = P < a.n_points;
+        const long Pc = valid ? P : a.n_points - 1;
+
+        // ---- inputs: 64 point features and 32 direction features of this lane's point
+        float fp[64], fd[32];
+        if constexpr (MODE == kModeX) {
+            const float* xr = a.x + Pc * (IDN_PTS_CH + IDN_VIEWS_CH);
+            static_for<64>([&](auto K) { fp[decltype(K)::value] = decltype(K)::value < IDN_PTS_CH ? xr[decltype(K)::value] : 0.0f; });
+            static_for<32>([&](auto K) { fd[decltype(K)::value] = decltype(K)::value < IDN_VIEWS_CH ? xr[IDN_PTS_CH + decltype(K)::value] : 0.0f; });
+        } else {
+            const long ray = Pc / a.S;
+            float p[3], v[3];
+            if constexpr (MODE == kModeRays) {
+                const float* rr = a.rays + ray * IDN_RAY_FLOATS;
+                const float zz = a.z[Pc];
+                p[0] = rr[0] + rr[3] * zz;  // product and sum rounded separately (-ffp-contract=off)
+                p[1] = rr[1] + rr[4] * zz;
+                p[2] = rr[2] + rr[5] * zz;
+                v[0] = rr[8];
+                v[1] = rr[9];
+                v[2] = rr[10];
+            } else {
+                p[0] = a.pts[Pc * 3 + 0];
+                p[1] = a.pts[Pc * 3 + 1];
+                p[2] = a.pts[Pc * 3 + 2];
+                v[0] = a.dirs[ray * 3 + 0];
+                v[1] = a.dirs[ray * 3 + 1];
+                v[2] = a.dirs[ray * 3 + 2];
+            }
+            encode<10, 64>(p, fp);
+            encode<4, 32>(v, fd);
+        }
+        // k-step fragments of the inputs: element j of k-step s, lane half h = feature 16s + (j&3) + 8(j>>2) + 4h
+        f32x4 pe_hi[4], pe_lo[4], pd_hi[2], pd_lo[2];
+        auto pack_feats = [&](const float* f, f32x4* ohi, f32x4* olo, auto NKS) {
+            static_for<decltype(NKS)::value>([&](auto S_) {
+                constexpr int s = decltype(S_)::value;
+                static_for<4>([&](auto W_) {
+                    constexpr int w = decltype(W_)::value;
+                    constexpr int j0 = 2 * w, j1 = 2 * w + 1;
+                    constexpr int k0 = 16 * s + (j0 & 3) + 8 * (j0 >> 2), k1 = 16 * s + (j1 & 3) + 8 * (j1 >> 2);
+                    const float x0 = h ? f[k0 + 4] : f[k0], x1 = h ? f[k1 + 4] : f[k1];
+                    float hw, lw;
+                    split2(x0, x1, hw, lw);
+                    ohi[s][w] = hw;
+                    olo[s][w] = lw;
+                });
+            });
+        };
+        pack_feats(fp, pe_hi, pe_lo, ic<4>{});
+        pack_feats(fd, pd_hi, pd_lo, ic<2>{});
+
+        BTile A[8], B[8], V[4];
+        f32x16 acc[2], pend;
+        auto tiles_hi = [](BTile* arr) { return [arr](auto S_) { constexpr int s = decltype(S_)::value; return arr[s >> 1].hi[s & 1]; }; };
+        auto tiles_lo = [](BTile* arr) { return [arr](auto S_) { constexpr int s = decltype(S_)::value; return arr[s >> 1].lo[s & 1]; }; };
+        auto pe_h = [&](auto S_) { return pe_hi[decltype(S_)::value]; };
+        auto pe_l = [&](auto S_) { return pe_lo[decltype(S_)::value]; };
+
+        // ---- pts_linears.0 : PE(64) -> 256
+        run_layer_bf<layer_f0(0), 8, 4, false>(A, nullptr, pend, acc, bias_h + bias_off(0), pe_h, pe_l, ws, fr);
+        // ---- pts_linears.1..4 (A -> B -> A -> B -> A); each layer first converts the previous layer's last tile
+#pragma unroll 1
+        for (int l = 1; l <= 3; l += 2) {
+            run_layer_bf<layer_f0(1), 8, 16, true>(B, &A[7], pend, acc, bias_h + l * 256, tiles_hi(A), tiles_lo(A), ws, fr);
+            run_layer_bf<layer_f0(2), 8, 16, true>(A, &B[7], pend, acc, bias_h + (l + 1) * 256, tiles_hi(B), tiles_lo(B), ws, fr);
+        }
+        // ---- pts_linears.5 : [PE(64) | 256] -> 256
+        run_layer_bf<layer_f0(5), 8, 20, true>(
+            B, &A[7], pend, acc, bias_h + bias_off(5),
+            [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 4) return pe_hi[s]; else return A[(s - 4) >> 1].hi[(s - 4) & 1]; },
+            [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 4) return pe_lo[s]; else return A[(s - 4) >> 1].lo[(s - 4) & 1]; },
+            ws, fr);
+        // ---- pts_linears.6, .7
+        run_layer_bf<layer_f0(6), 8, 16, true>(A, &B[7], pend, acc, bias_h + bias_off(6), tiles_hi(B), tiles_lo(B), ws, fr);
+        run_layer_bf<layer_f0(7), 8, 16, true>(B, &A[7], pend, acc, bias_h + bias_off(7), tiles_hi(A), tiles_lo(A), ws, fr);
+        // ---- views_linears.0 (+ alpha_linear as channel 128): [256 | dirPE(32)] -> 160.
+        //      Tiles 0..3 are hidden units; tile 4 (last) is never converted: its row 0 is sigma.
+        BTile Vx[5];
+        run_layer_bf<layer_f0(8), 5, 18, true>(
+            Vx, &B[7], pend, acc, bias_h + bias_off(8),
+            [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 16) return B[s >> 1].hi[s & 1]; else return pd_hi[s - 16]; },
+            [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 16) return B[s >> 1].lo[s & 1]; else return pd_lo[s - 16]; },
+            ws, fr);
+        const float sigma = pend[0];  // channel 128 = tile 4, register 0, lane half 0
+        static_for<4>([&](auto T) { V[decltype(T)::value] = Vx[decltype(T)::value]; });
+        // ---- views_linears.1, .2 : 128 -> 128 (V -> A[0..3] -> V)
+        run_layer_bf<layer_f0(9), 4, 8, false>(A, nullptr, pend, acc, bias_h + bias_off(9), tiles_hi(V), tiles_lo(V), ws, fr);
+        run_layer_bf<layer_f0(10), 4, 8, true>(V, &A[3], pend, acc, bias_h + bias_off(10), tiles_hi(A), tiles_lo(A), ws, fr);
+        // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile)
+        BTile none[1];
+        run_layer_bf<layer_f0(11), 1, 8, true>(none, &V[3], pend, acc, bias_h + bias_off(11), tiles_hi(V), tiles_lo(V), ws, fr);
+        finish_pass<kUsedFrags>(ws);
+
+        if (valid && h == 0) {
+            f32x4 o;
+            o.x = pend[0];
+            o.y = pend[1];
+            o.z = pend[2];
+            o.w = sigma;
+            *reinterpret_cast<f32x4*>(a.raw + P * 4) = o;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+}
+
+int launch_mlp_bf16x3(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
+                      const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s) {
+    if (n_points <= 0) return IDN_OK;
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        IDN_HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        IDN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModeRays>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModeX>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModePts>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+        num_cu = prop.multiProcessorCount;
+    }
+    const int64_t ntiles = (n_points + 127) / 128;
+    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
+    MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, nullptr, 0};
+    ProfScope prof(s, n_points);
+    if (x)
+        hipLaunchKernelGGL((mlp_bf16x3_kernel<kModeX>), dim3(grid), dim3(256), kMlpLds, s, a);
+    else if (pts)
+        hipLaunchKernelGGL((mlp_bf16x3_kernel<kModePts>), dim3(grid), dim3(256), kMlpLds, s, a);
+    else
+        hipLaunchKernelGGL((mlp_bf16x3_kernel<kModeRays>), dim3(grid), dim3(256), kMlpLds, s, a);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+}  // namespace idn

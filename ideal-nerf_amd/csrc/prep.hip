@@ -47,9 +47,67 @@ __global__ void pack_f32_kernel(PackDesc d, float4* out) {
     out[gid] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-int launch_pack_f32(const idn_facenerf_params& p, float* packed, hipStream_t s) {
-    const int C = p.dim_aud + p.dim_expr + p.dim_latent;
+// bf16x3 stream: fragment pair (2p, 2p+1) of a tile = hi / lo halves of one 16-channel k-step.
+// Lane (i, h) holds 8 bf16: element j = W[32t+i][channel 16 ks + (j&3) + 8 (j>>2) + 4 h]
+// (the order in which an accumulator tile's registers 8s..8s+7 become a B operand).
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;  // finite inputs only (weights)
+}
+__global__ void pack_bf16x3_kernel(PackDesc d, uint4* out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= kStreamFrags * 64) return;
+    const int f = gid >> 6, lane = gid & 63;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (f < kUsedFrags) {
+        int l = 0;
+        while (l + 1 < kNumLayers && f >= d.L[l + 1].f0) ++l;
+        const PackLayer& L = d.L[l];
+        const int rel = f - L.f0;
+        const int t = rel / L.kg, gg = rel - t * L.kg;
+        const int ks = gg >> 1, part = gg & 1;  // part 0 = hi, 1 = lo
+        const int n = 32 * t + (lane & 31), h = lane >> 5;
+        const int ks0 = L.kg0 >> 1;             // k-steps of source 0
+        const int src = ks < ks0 ? 0 : 1;
+        const int kbase = 16 * (src ? ks - ks0 : ks) + 4 * h;
+        for (int j = 0; j < 8; ++j) {
+            const int k = kbase + (j & 3) + 8 * (j >> 2);
+            float v = 0.f;
+            if (k < L.kvalid[src]) {
+                if (n < L.rows) v = L.w[(long)n * L.ld + L.col0[src] + k];
+                else if (L.w_extra && n == L.extra_at && src == 0) v = L.w_extra[k];
+            }
+            const unsigned hi = bf16_rne(v);
+            const unsigned bits = part == 0 ? hi : bf16_rne(v - __uint_as_float(hi << 16));
+            w[j >> 1] |= bits << (16 * (j & 1));
+        }
+    }
+    out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+static void fill_pack_desc(const idn_facenerf_params& p, PackDesc& d);
+
+int launch_pack_bf16x3(const idn_facenerf_params& p, float* packed, hipStream_t s) {
     PackDesc d;
+    fill_pack_desc(p, d);
+    const int total = kStreamFrags * 64;
+    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d, reinterpret_cast<uint4*>(packed));
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+int launch_pack_f32(const idn_facenerf_params& p, float* packed, hipStream_t s) {
+    PackDesc d;
+    fill_pack_desc(p, d);
+    const int total = kStreamFrags * 64;
+    hipLaunchKernelGGL(pack_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d,
+                       reinterpret_cast<float4*>(packed));
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+static void fill_pack_desc(const idn_facenerf_params& p, PackDesc& d) {
+    const int C = p.dim_aud + p.dim_expr + p.dim_latent;
     for (int l = 0; l < kNumLayers; ++l) {
         PackLayer& L = d.L[l];
         L.w_extra = nullptr;
@@ -77,11 +135,6 @@ int launch_pack_f32(const idn_facenerf_params& p, float* packed, hipStream_t s) 
             L.w = p.rgb_w; L.ld = IDN_W / 2; L.rows = 3; L.kvalid[0] = IDN_W / 2;
         }
     }
-    const int total = kStreamFrags * 64;
-    hipLaunchKernelGGL(pack_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d,
-                       reinterpret_cast<float4*>(packed));
-    IDN_HIP_CHECK(hipGetLastError());
-    return IDN_OK;
 }
 
 struct FoldDesc {

@@ -10,6 +10,18 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .._lib import IDN_PREC_BF16X3, IDN_PREC_F32
+
+PRECISIONS = {"f32": IDN_PREC_F32, "bf16x3": IDN_PREC_BF16X3}
+_default_precision = ["f32"]
+
+
+def set_default_precision(name: str):
+    """Arithmetic of the MLP contraction for modules created afterwards: "f32" (exact fp32
+    MFMA) or "bf16x3" (three bf16 MFMAs per product, ~1.5e-5 relative on the output)."""
+    if name not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+    _default_precision[0] = name
 
 
 class FaceNeRF(nn.Module):
@@ -34,8 +46,9 @@ class FaceNeRF(nn.Module):
         self.feature_linear = nn.Linear(W, W)  # present for checkpoint compatibility; never applied upstream
         self.alpha_linear = nn.Linear(W, 1)
         self.rgb_linear = nn.Linear(W // 2, 3)
-        self._packed = None
-        self._packed_key = None
+        self.precision = _default_precision[0]   # inference arithmetic; training always runs fp32
+        self._packed = {}
+        self._packed_key = {}
 
     # -- kernel-side views of the parameters ------------------------------------------
     def _param_key(self):
@@ -45,15 +58,20 @@ class FaceNeRF(nn.Module):
         sd = {k: v for k, v in self.named_parameters()}
         return ops.params_struct(sd, self.dim_aud, self.dim_expr, self.dim_latent)
 
-    def packed_weights(self) -> torch.Tensor:
-        """MFMA-fragment weight stream, rebuilt only when a parameter changed."""
+    def packed_weights(self, precision: str = None) -> torch.Tensor:
+        """MFMA-fragment weight stream for `precision`, rebuilt only when a parameter changed."""
+        precision = precision or self.precision
         key = self._param_key()
-        if self._packed is None or self._packed_key != key:
+        if self._packed.get(precision) is None or self._packed_key.get(precision) != key:
             dev = self.alpha_linear.weight.device
             with torch.no_grad():
-                self._packed = ops.pack_weights(self.kernel_params(), dev)
-            self._packed_key = key
-        return self._packed
+                self._packed[precision] = ops.pack_weights(self.kernel_params(), dev, PRECISIONS[precision])
+            self._packed_key[precision] = key
+        return self._packed[precision]
+
+    @property
+    def prec_code(self) -> int:
+        return PRECISIONS[self.precision]
 
     def folded_bias(self, aud, expr=None, latent_code=None) -> torch.Tensor:
         self._check_cond(aud, expr, latent_code)
@@ -76,4 +94,5 @@ class FaceNeRF(nn.Module):
             return facenerf_apply(self, x, aud, expr, latent_code)
         with torch.no_grad():
             folded = self.folded_bias(aud, expr, latent_code)
-            return ops.facenerf_fwd(self.packed_weights(), folded, x.detach().to(torch.float32).contiguous())
+            return ops.facenerf_fwd(self.packed_weights(), folded, x.detach().to(torch.float32).contiguous(),
+                                    self.prec_code)

@@ -723,3 +723,80 @@ def test_backward_kernels_vs_fp64_on_saved_activations(idn, dev):
         for k in G:
             assert rel_err(grads[k], G[k]) < 5e-6, (S, k)
         assert rel_err(d_aud, d_cond[:64]) < 5e-6 and rel_err(d_lat, d_cond[64 + 79:]) < 5e-6
+
+
+# --------------------------------------------------------------------------- bf16x3 arithmetic mode
+BF16X3 = 1  # IDN_PREC_BF16X3
+
+
+def test_bf16x3_facenerf_golden(idn, dev, golden):
+    """Three bf16 MFMAs per product: ~2^-16 per product, ~1.5e-5 on the output."""
+    g = golden("facenerf")
+    for name, v in (("c235", dict(dim_aud=64, dim_expr=76, dim_latent=32)), ("c169", dict(dim_aud=106, dim_expr=0, dim_latent=0))):
+        dims = oracle.facenerf_dims(**v)
+        params = oracle.xavier_facenerf_params(11, dims)
+        sd = {k: t.to(dev).contiguous() for k, t in params.items()}
+        ps = idn.ops.params_struct(sd, dims["dim_aud"], dims["dim_expr"], dims["dim_latent"])
+        packed = idn.ops.pack_weights(ps, dev, BF16X3)
+        opt = lambda k: T(g[k]).to(dev) if k in g else None
+        folded = idn.ops.fold_conditioning(ps, T(g[name + "_aud"]).to(dev), opt(name + "_expr"), opt(name + "_latent"), dev)
+        out = idn.ops.facenerf_fwd(packed, folded, T(g[name + "_x"]).to(dev), BF16X3)
+        err = rel_err(out, g[name + "_out"])
+        print(f"\nbf16x3 FaceNeRF {name}: max rel err vs reference = {err:.2e}")
+        assert err < 5e-5
+
+
+@pytest.mark.parametrize("n", [1, 33, 130, 4099])
+def test_bf16x3_ragged(idn, dev, n):
+    dims = oracle.facenerf_dims()
+    params = scale_sigma(oracle.xavier_facenerf_params(5, dims), 30.0, 0.1)
+    rs = np.random.RandomState(n)
+    x = T(rs.uniform(-1, 1, size=(n, 90)).astype(np.float32))
+    aud, expr, lat = (T(rs.standard_normal(k).astype(np.float32)) for k in (64, 76, 32))
+    with torch.no_grad():
+        ref = oracle.facenerf_forward(params, x, aud, expr, lat, dims)
+    sd = {k: t.to(dev).contiguous() for k, t in params.items()}
+    ps = idn.ops.params_struct(sd, 64, 76, 32)
+    out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, BF16X3),
+                               idn.ops.fold_conditioning(ps, aud.to(dev), expr.to(dev), lat.to(dev), dev), x.to(dev), BF16X3)
+    assert rel_err(out, ref) < 1e-4
+
+
+def test_bf16x3_render_frame32_golden(idn, dev, golden):
+    """End to end in bf16x3: RGB within the 1e-4 budget, PSNR vs the reference's frame."""
+    g = golden("frame32")
+    dims = oracle.facenerf_dims()
+    pc = scale_sigma(oracle.xavier_facenerf_params(2, dims))
+    pf = scale_sigma(oracle.xavier_facenerf_params(3, dims))
+    syn = oracle.synthetic_frame(32, 32, seed=0, dims=dims)
+    cond = [t.to(dev) for t in (syn["aud"], syn["expr"], syn["latent"])]
+    nets = []
+    for p in (pc, pf):
+        sd = {k: t.to(dev).contiguous() for k, t in p.items()}
+        ps = idn.ops.params_struct(sd, 64, 76, 32)
+        nets.append((idn.ops.pack_weights(ps, dev, BF16X3), idn.ops.fold_conditioning(ps, *cond, dev), sd))
+    rays = idn.ops.frame_rays(syn["c2w"], 32, 32, syn["focal"], NEAR, FAR, device=dev)
+    out = idn.ops.render_rays_fwd(rays, syn["bc"].reshape(-1, 3).to(dev), nets[0][0], nets[0][1], nets[1][0], nets[1][1],
+                                  torch.linspace(0.0, 1.0, 64).to(dev), torch.linspace(0.0, 1.0, 128).to(dev), 128,
+                                  taps=True, precision=BF16X3)
+    e_rgb, e_rgb0 = rel_err(out["rgb_map"], g["rgb"].reshape(-1, 3)), rel_err(out["rgb0"], g["rgb0"].reshape(-1, 3))
+    flips = (out["tap_inds"].cpu().numpy() != g["tap_inds"].astype(np.int64)).mean()
+    mse = float(((out["rgb_map"].cpu().numpy() - g["rgb"].reshape(-1, 3)) ** 2).mean())
+    print(f"\nbf16x3 frame32: rgb err {e_rgb:.2e}, rgb0 err {e_rgb0:.2e}, index flip rate {flips:.2e}, "
+          f"PSNR vs reference {10 * np.log10(1.0 / max(mse, 1e-30)):.1f} dB")
+    assert e_rgb < RGB_TOL and e_rgb0 < RGB_TOL
+    assert flips < FLIP_TOL
+    assert rel_err(out["tap_raw_coarse"][:128], g["tap_raw_coarse"]) < 1e-4
+
+
+def test_bf16x3_module_precision_switch(idn, dev, golden):
+    g = golden("facenerf")
+    net = idn.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76).to(dev)
+    net.load_state_dict(oracle.xavier_facenerf_params(11, oracle.facenerf_dims()))
+    args = [T(g["c235_" + k]).to(dev) for k in ("x", "aud", "expr", "latent")]
+    with torch.no_grad():
+        o32 = net(*args)
+        net.precision = "bf16x3"
+        o16 = net(*args)
+    assert rel_err(o32, g["c235_out"]) < 1e-5 and rel_err(o16, g["c235_out"]) < 5e-5
+    assert not torch.equal(o32, o16)
