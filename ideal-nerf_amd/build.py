@@ -34,20 +34,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_diag(verbose=True):
-    """Diagnostic variant (cycle stamps in the MLP kernel): libidealnerf_diag.so.  Never loaded by
-    the package unless IDN_LIB points at it; used by tools/diag_mlp.py only."""
-    obj = os.path.join(OBJ, "diag")
+def build_diag(verbose=True, define="-DIDN_DIAG", tag="diag"):
+    """Diagnostic variants: libidealnerf_diag.so (cycle stamps in the MLP kernel) or, with
+    define=-DIDN_DIAG_NOSTREAM, libidealnerf_nostream.so (timing-only: the weight prefetch is
+    dropped after the prologue, outputs are garbage).  Never loaded by the package unless IDN_LIB
+    points at them."""
+    obj = os.path.join(OBJ, tag)
     os.makedirs(obj, exist_ok=True)
     objs = []
     for src in SOURCES:
         o = os.path.join(obj, src.replace(".hip", ".o"))
-        cmd = [hipcc()] + FLAGS + ["-DIDN_DIAG", "-c", os.path.join(CSRC, src), "-o", o]
+        cmd = [hipcc()] + FLAGS + [define, "-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         objs.append(o)
-    lib = os.path.join(HERE, "libidealnerf_diag.so")
+    lib = os.path.join(HERE, f"libidealnerf_{tag}.so")
     subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
     return lib
 
@@ -84,5 +86,7 @@ def build(force=False, verbose=True):
 if __name__ == "__main__":
     if "--diag" in sys.argv:
         print(build_diag())
+    elif "--nostream" in sys.argv:
+        print(build_diag(define="-DIDN_DIAG_NOSTREAM", tag="nostream"))
     else:
         print(build(force="--force" in sys.argv))

@@ -30,8 +30,13 @@ namespace idn {
 // ---------------------------------------------------------------------------
 constexpr int kFragBytes = 1024;
 constexpr int kFragFloats = 256;
+// Ring geometry.  Measured on the bf16x3 kernel (512^2 frame): 2 x 64 KiB 4.12e8 samples/s,
+// 4 x 32 KiB (prefetch three slices ahead, counted vmcnt) 3.98e8: the extra barriers cost more
+// than the deeper prefetch buys; the stream's cost is its issue/bandwidth (timing-only build
+// without it: 4.70e8), not its latency.
 constexpr int kSliceFrags = 64;                 // one LDS ring slot = 64 KiB
-constexpr int kRingFrags = 2 * kSliceFrags;     // 128 KiB ring
+constexpr int kRingSlots = 2;                   // slices are fetched kRingSlots-1 ahead of their use
+constexpr int kRingFrags = kRingSlots * kSliceFrags;  // 128 KiB ring
 constexpr int kSliceBytes = kSliceFrags * kFragBytes;
 
 constexpr int kNumLayers = 12;  // pts0..7, views0(+alpha), views1, views2, rgb
@@ -45,10 +50,12 @@ constexpr int layer_f0(int l) {
     return f;
 }
 constexpr int kUsedFrags = layer_f0(kNumLayers);                                  // 2244
-constexpr int kNumSlices = ((kUsedFrags + kSliceFrags - 1) / kSliceFrags + 1) / 2 * 2;  // even: 36
+constexpr int kNumSlices =
+    ((kUsedFrags + kSliceFrags - 1) / kSliceFrags + kRingSlots - 1) / kRingSlots * kRingSlots;  // 36
 constexpr int kStreamFrags = kNumSlices * kSliceFrags;                            // 2304
 static_assert(kUsedFrags == 2244, "layer table changed");
-static_assert(kNumSlices % 2 == 0, "ring parity must be static across passes");
+static_assert(kNumSlices % kRingSlots == 0, "slot of a slice must be static across passes");
+static_assert(kRingFrags == 128, "FragReader addresses the ring as two 64-fragment halves");
 
 // Folded bias block: one float per output channel, natural channel order
 // (accumulator register 4q+j of tile t, lane half h <-> channel 32 t + 8 q + 4 h + j).

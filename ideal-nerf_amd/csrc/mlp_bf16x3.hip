@@ -91,6 +91,8 @@ template <int F0, int NT, int KS, bool DEFER, class BHi, class BLo>
 __device__ __forceinline__ void run_layer_bf(BTile* out, BTile* deferred, f32x16& pend, f32x16 (&acc)[2],
                                              const float* bias_half, BHi&& bhi, BLo&& blo, WStream& ws, FragReader& fr) {
     constexpr int NP = NT * KS;
+    // the last layer of a pass must not prefetch past itself (see run_layer in mlp_f32.hip)
+    constexpr bool LAST = (F0 + 2 * NP == kUsedFrags);
     static_assert(F0 % 2 == 0, "fragments are consumed in (hi, lo) pairs");
     bias_tile(acc[0], bias_half);
     const SideBf<NT, KS, DEFER> side{out, deferred, &pend, &acc[0], bias_half};
@@ -105,17 +107,15 @@ __device__ __forceinline__ void run_layer_bf(BTile* out, BTile* deferred, f32x16
         constexpr int t = pi / KS, s = pi % KS;
         constexpr int f = F0 + 2 * pi;
         constexpr bool next_crosses = ((f + 2) % kSliceFrags == 0);
-        constexpr int jpos = (f % kSliceFrags) / 2;
-        constexpr int slot = (f / kSliceFrags) & 1;
         f32x4 n0 = a0, n1 = a1;
-        if constexpr (!next_crosses) {
+        if constexpr (!next_crosses && !(LAST && pi + 1 == NP)) {
             n0 = fr.template issue<f + 2>();
             n1 = fr.template issue<f + 3>();
             FragReader::retire<2>(a0, a1);
         } else {
             FragReader::retire<0>(a0, a1);
         }
-        if constexpr (jpos < kPieces) ws.template issue_piece<slot ^ 1, jpos>();
+        ws.template step_piece<f>();
         const f32x4 bh = bhi(ic<s>{}), bl = blo(ic<s>{});
         acc[t & 1] = mfma_bf(a0, bh, acc[t & 1]);   // hi * hi
         side(ic<t>{}, ic<s>{}, ic<0>{});
@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
     const int m = lane & 31, h = lane >> 5;
 
     for (int i = tid; i < kBiasFloats; i += 256) bias_s[i] = a.bias[i];
+    __syncthreads();  // the bias block is read (by other waves) before the first slice barrier
 
     Diag dg;
     WStream ws;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
     ws.gnext = ws.gbase;
     ws.next_slice = 0;
     ws.ring_wave = ring + wave * kFragBytes;
-    ws.issue_rest<0, 0>();
+    ws.prologue();
 
     FragReader fr;
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;

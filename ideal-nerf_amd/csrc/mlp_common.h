@@ -54,12 +54,17 @@ struct Diag {};
 // ---------------------------------------------------------------------------
 // weight stream: global -> LDS ring
 //
-// The ring holds two 64 KiB slices.  A slice is fetched by 16 "pieces" (one
-// global_load_lds_dwordx4 per wave each = 4 KiB per piece); the pieces of slice s+1 are
-// issued one per fragment-pair step during the first half of slice s, so their address
-// arithmetic rides in MFMA shadows instead of stalling the restart after a barrier.
+// The ring holds kRingSlots slices (idn_internal.h).  A slice is fetched by "pieces" (one
+// global_load_lds_dwordx4 per wave each = 4 KiB per piece); while slice s is consumed, the
+// pieces of slice s + kRingSlots-1 are issued, one per fragment-pair step, into the slot slice
+// s-1 just vacated.  A slice is opened by a COUNTED wait + raw barrier: s_waitcnt vmcnt(N)
+// leaves the N pieces of the younger slices in flight (N = 0 for the two-slot ring).  Other
+// vector-memory operations of the wave only make the counted wait stricter.
 // ---------------------------------------------------------------------------
-constexpr int kPieces = kSliceFrags / 4;  // 16
+constexpr int kPieces = kSliceFrags / 4;                    // pieces per slice
+constexpr int kAhead = kRingSlots - 1;                      // slices in flight ahead of the consumer
+constexpr int kVmcntOpen = (kAhead - 1) * kPieces;          // younger pieces allowed in flight at a barrier
+static_assert(kVmcntOpen == 0 || kVmcntOpen == 8 || kVmcntOpen == 16, "add the s_waitcnt literal below");
 
 struct WStream {
     Diag* dg;
@@ -67,6 +72,9 @@ struct WStream {
     const char* gnext;  // same, for the slice currently being fetched
     int next_slice;
     char* ring_wave;    // ring + wave * 1 KiB (wave-uniform LDS destination base)
+#ifdef IDN_DIAG_NOSTREAM
+    bool pass_done = true;  // set false to drop all prefetch pieces after the prologue
+#endif
 
     __device__ __forceinline__ void advance() {
         gnext += kSliceBytes;
@@ -77,6 +85,9 @@ struct WStream {
     }
     template <int SLOT, int J>
     __device__ __forceinline__ void issue_piece() {
+#ifdef IDN_DIAG_NOSTREAM  // timing-only experiment: what does the weight stream cost? (outputs are garbage)
+        if (pass_done)
+#endif
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gnext + J * 4096),
                                          LDS_PTR(ring_wave + SLOT * kSliceBytes + J * 4096), 16, 0, 0);
         if constexpr (J == kPieces - 1) advance();
@@ -85,12 +96,31 @@ struct WStream {
     __device__ __forceinline__ void issue_rest() {
         static_for<kPieces - J0>([&](auto I) { issue_piece<SLOT, J0 + decltype(I)::value>(); });
     }
-    // every wave's share of the slice to be read next has landed (vmcnt(0) precedes the
-    // barrier) and every wave is done reading the other slot
+    // kernel start: slices 0 .. kAhead-1 into slots 0 .. kAhead-1
+    __device__ __forceinline__ void prologue() {
+        static_for<kAhead>([&](auto S_) { issue_rest<decltype(S_)::value, 0>(); });
+#ifdef IDN_DIAG_NOSTREAM
+        pass_done = false;
+#endif
+    }
+    // Open the next slice: this wave's pieces of it have landed (all but the 16 youngest
+    // vector-memory operations are complete); after the barrier every wave's have, and every
+    // wave is done reading the slot the next pieces will overwrite.
     __device__ __forceinline__ void open_slice() {
         DIAG_BEGIN(*dg);
-        __syncthreads();
+        if constexpr (kVmcntOpen == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (kVmcntOpen == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         DIAG_END(*dg, kDgBarrier);
+    }
+    // the piece (if any) to issue at the pair-step that consumes fragment F
+    template <int F>
+    __device__ __forceinline__ void step_piece() {
+        constexpr int jpos = (F % kSliceFrags) / 2;
+        constexpr int slot = (F / kSliceFrags + kAhead) % kRingSlots;
+        if constexpr (jpos < kPieces) issue_piece<slot, jpos>();
     }
 };
 
@@ -125,15 +155,17 @@ struct FragReader {
     }
 };
 
-// End of a pass: the pieces of the next pass's first slice that the (short) last slice did
-// not get to issue.
+// End of a pass: walk the unused tail of the stream (padding) without reading it, so that the
+// barriers and prefetch pieces scheduled on those positions still happen and the next pass
+// finds its first kAhead slices in flight.
 template <int F_END>
 __device__ __forceinline__ void finish_pass(WStream& ws) {
-    static_assert(F_END % kSliceFrags != 0 && (F_END + kSliceFrags - 1) / kSliceFrags == kNumSlices,
-                  "the last consumed slice must be the stream's last and partially used");
-    constexpr int jpos = (F_END % kSliceFrags) / 2;
-    constexpr int slot = (F_END / kSliceFrags) & 1;
-    if constexpr (jpos < kPieces) ws.template issue_rest<slot ^ 1, jpos>();
+    static_assert(F_END % 2 == 0, "pairs");
+    static_for<(kStreamFrags - F_END) / 2>([&](auto I) {
+        constexpr int f = F_END + 2 * decltype(I)::value;
+        if constexpr (f % kSliceFrags == 0) ws.open_slice();
+        ws.template step_piece<f>();
+    });
 }
 
 // acc[4q..4q+3] of one tile <- bias of channels 32t + 8q + 4h + 0..3

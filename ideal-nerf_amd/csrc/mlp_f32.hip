@@ -30,7 +30,11 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 //     there issues while the matrix pipe is busy (finished tiles' ReLU, the next tile's bias).
 // F0 = index of the layer's first fragment in the stream.  On entry fr.pref* hold pair F0
 // in flight unless F0 opens a slice; on exit they hold pair F0 + NT*KG likewise.
-template <int F0, int NT, int KG, class BGet, class Side>
+// LAST: the final layer of a pass must not prefetch the pair after its own last one -- nobody
+// would retire that read, the compiler would treat its destination registers as dead and
+// reuse them (e.g. as a global address) while the LDS data is still on its way
+// (tools/audit_asm_loads.py checks the ISA for this).
+template <int F0, int NT, int KG, bool LAST = false, class BGet, class Side>
 __device__ __forceinline__ void run_layer(f32x16 (&out)[NT], BGet&& bget, WStream& ws, FragReader& fr, Side&& side) {
     constexpr int STEPS = KG / 2, NP = NT * STEPS;
     static_assert(KG % 2 == 0 && F0 % 2 == 0, "fragments are consumed in pairs");
@@ -45,17 +49,15 @@ __device__ __forceinline__ void run_layer(f32x16 (&out)[NT], BGet&& bget, WStrea
         constexpr int t = pi / STEPS, s = pi % STEPS, g0 = 2 * s, g1 = g0 + 1;
         constexpr int f = F0 + 2 * pi;
         constexpr bool next_crosses = ((f + 2) % kSliceFrags == 0);
-        constexpr int jpos = (f % kSliceFrags) / 2;   // position of this pair inside its slice
-        constexpr int slot = (f / kSliceFrags) & 1;
         f32x4 n0 = a0, n1 = a1;
-        if constexpr (!next_crosses) {
+        if constexpr (!next_crosses && !(LAST && pi + 1 == NP)) {
             n0 = fr.template issue<f + 2>();
             n1 = fr.template issue<f + 3>();
             FragReader::retire<2>(a0, a1);
         } else {
             FragReader::retire<0>(a0, a1);
         }
-        if constexpr (jpos < kPieces) ws.template issue_piece<slot ^ 1, jpos>();
+        ws.template step_piece<f>();
         out[t] = mfma(a0.x, bget(ic<g0>{}, ic<0>{}), out[t]);
         out[t] = mfma(a0.y, bget(ic<g0>{}, ic<1>{}), out[t]);
         out[t] = mfma(a0.z, bget(ic<g0>{}, ic<2>{}), out[t]);
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
     const int m = lane & 31, h = lane >> 5;
 
     for (int i = tid; i < kBiasFloats; i += 256) bias_s[i] = a.bias[i];
+    __syncthreads();  // the bias block is read (by other waves) before the first slice barrier
 
     Diag dg;
     WStream ws;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
     ws.gnext = ws.gbase;
     ws.next_slice = 0;
     ws.ring_wave = ring + wave * kFragBytes;
-    ws.issue_rest<0, 0>();  // slice 0 -> slot 0
+    ws.prologue();
 
     FragReader fr;
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
@@ -255,13 +258,14 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         auto layer = [&](auto F0c, auto NTc, auto KGc, auto DEFERc, auto& out, f32x16* deferred, auto&& bget,
                          const float* bias_l, int save_idx) {
             constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KG = decltype(KGc)::value;
+            constexpr bool LAST = (F0 + NT * KG == kUsedFrags);
             constexpr bool DEFER = decltype(DEFERc)::value != 0;
             DIAG_BEGIN(dg);
             if constexpr (SAVE) load_bias<NT>(out, bias_l);
             else bias_tile(out[0], bias_l);
             DIAG_END(dg, kDgBoundary);
             if constexpr (SAVE) {
-                run_layer<F0, NT, KG>(out, bget, ws, fr, NoSide{});
+                run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, NoSide{});
                 DIAG_BEGIN(dg);
                 if (save_idx >= 0) {  // hidden layer: ReLU + record
                     relu_tiles<NT>(out);
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
                 }
                 DIAG_END(dg, kDgBoundary);
             } else {
-                run_layer<F0, NT, KG>(out, bget, ws, fr, LayerSide<NT, KG / 2, DEFER>{&out[0], deferred, bias_l});
+                run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, LayerSide<NT, KG / 2, DEFER>{&out[0], deferred, bias_l});
             }
         };
         constexpr bool D = !SAVE;  // deferred last-tile ReLU only exists on the inference path

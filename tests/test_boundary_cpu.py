@@ -197,3 +197,31 @@ def test_gather_rows_gloo_two_ranks(H):
         p.join(120)
         assert p.exitcode == 0
     assert list(ok) == [1, 1]
+
+
+def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
+    """The MLP kernels read weight fragments with inline-asm ds_read_b128 retired by counted waits
+    (DESIGN.md): compile both kernels to ISA and check that no compiler-generated instruction
+    reads or writes a destination register while its read is still in flight
+    (tools/audit_asm_loads.py; a dangling prefetch once let hipcc reuse such registers as a
+    global address -> memory fault)."""
+    import concurrent.futures
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "ideal-nerf_amd", "csrc")
+
+    def compile_s(name):
+        out = tmp_path / (name + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                        "--cuda-device-only", os.path.join(csrc, name + ".hip"), "-o", str(out)], check=True)
+        return str(out)
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
+        files = list(ex.map(compile_s, ["mlp_f32", "mlp_bf16x3"]))
+    for f in files:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), f, "mlp_"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert "0 suspicious touches" in r.stdout

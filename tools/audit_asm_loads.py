@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Audit hipcc output for the in-flight window of inline-asm LDS reads.
+
+An `asm volatile("ds_read_b128 %0, ...")` destination counts, for the compiler, as written at
+the end of the asm statement -- but the data lands ~100+ cycles later.  Any compiler-generated
+instruction that reads or writes those registers before the asm `s_waitcnt lgkmcnt(N)` that
+retires them sees/destroys garbage (cdna_hip_programming.md 5.7).  This script walks each
+kernel in a .s file in program order (straight-line approximation), tracks the destination
+ranges of asm ds_reads and reports every non-asm instruction that touches a range while it is
+in flight.  Usage: audit_asm_loads.py file.s [kernel-name-substring]
+"""
+import re, sys
+
+def regs(tok):
+    out = set()
+    for m in re.finditer(r'\b([va])\[(\d+):(\d+)\]', tok):
+        out |= {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    for m in re.finditer(r'\b([va])(\d+)\b', tok):
+        out.add((m.group(1), int(m.group(2))))
+    return out
+
+def audit(lines, name):
+    inflight = []   # list of (regset, line_no) in issue order
+    in_asm = False
+    bad = 0
+    for no, ln in lines:
+        s = ln.strip()
+        if s.startswith(';;#ASMSTART') or '#ASMSTART' in s:
+            in_asm = True; continue
+        if '#ASMEND' in s:
+            in_asm = False; continue
+        if not s or s.startswith(';') or s.startswith('.') or s.endswith(':'):
+            continue
+        code = s.split(';')[0]
+        if in_asm:
+            if code.startswith('ds_read_b128'):
+                dst = code.split()[1].rstrip(',')
+                inflight.append((regs(dst), no))
+            elif code.startswith('s_waitcnt'):
+                m = re.search(r'lgkmcnt\((\d+)\)', code)
+                if m:
+                    keep = int(m.group(1))
+                    inflight = inflight[len(inflight) - keep:] if keep else []
+            continue
+        if code.startswith('s_waitcnt') and 'lgkmcnt(0)' in code:
+            inflight = []   # compiler's own full LDS wait retires everything
+            continue
+        if code.startswith('s_barrier') or code.startswith('s_cbranch') or code.startswith('s_branch'):
+            continue
+        touched = regs(code)
+        for rs, at in inflight:
+            hit = touched & rs
+            if hit:
+                bad += 1
+                if bad <= 12:
+                    print(f"  {name}: line {no}: `{code.strip()}` touches {sorted(hit)[:4]} (asm ds_read at line {at} still in flight)")
+    return bad
+
+def main():
+    path = sys.argv[1]
+    want = sys.argv[2] if len(sys.argv) > 2 else ''
+    cur, name, total = [], None, 0
+    for no, ln in enumerate(open(path), 1):
+        m = re.match(r'^(_Z\w+):', ln)
+        if m:
+            name, cur = m.group(1), []
+        if name:
+            cur.append((no, ln))
+            if 's_endpgm' in ln:
+                if want in name and 'kernel' in name:
+                    b = audit(cur, name[:40])
+                    print(f"{name[:60]}: {b} suspicious touches")
+                    total += b
+                name = None
+    sys.exit(1 if total else 0)
+
+if __name__ == '__main__':
+    main()
