@@ -311,6 +311,35 @@ def main():
     finally:
         aen.raw2outputs, aen.sample_pdf = real_r2o, real_sp
 
+    # ---- L4: config files through the reference's own flag parser -------------------------
+    # (configargparse is absent; it turns `key = value` lines into `--key value` arguments, which is
+    # what is fed to the reference's argparse-based parser here.)  Stored: the resolved values, or the
+    # fact that the parser rejected the file (stale keys), for a handful of shipped configs.
+    import glob
+    import io
+    import contextlib
+    import json
+    cfg_out = {}
+    for path in sorted(glob.glob(os.path.join(REF, "NeRFs/HeadNeRF/configs/audio_expr_nerf/*/*.txt")) +
+                       glob.glob(os.path.join(REF, "NeRFs/HeadNeRF/configs/audio_expr_nerf/*/*/*.txt"))):
+        lines = [l.strip() for l in open(path) if l.strip() and l.strip()[0] not in "#;"]
+        argv = []
+        for l in lines:
+            if "=" in l:
+                k, v = [t.strip() for t in l.split("=", 1)]
+                argv += ["--" + k, v]
+            else:
+                argv += ["--" + l]  # a bare key is a switch
+        rel = os.path.relpath(path, REF)
+        try:
+            with contextlib.redirect_stderr(io.StringIO()):
+                ns = helper.config_parser().parse_args(argv)
+            cfg_out[rel] = {"lines": lines, "parsed": {k: v for k, v in vars(ns).items() if k != "config"}}
+        except SystemExit:
+            cfg_out[rel] = {"lines": lines, "parsed": None}
+    with open(os.path.join(HERE, "configs_parsed.json"), "w") as f:
+        json.dump(cfg_out, f, indent=0, sort_keys=True)
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f"{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:8.1f} KiB")

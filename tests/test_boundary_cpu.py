@@ -225,3 +225,61 @@ def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
         assert "0 suspicious touches" in r.stdout
+
+
+def test_config_files_parse_like_the_reference(idn):
+    """Every shipped audio_expr_nerf config, resolved by the reference's own parser (golden), vs
+    idealnerf_amd.config: same values, and the same files are rejected (stale keys)."""
+    import json
+    from idealnerf_amd import config
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "configs_parsed.json")))
+    assert len(gold) >= 20
+    n_rejected = 0
+    for rel, g in gold.items():
+        text = "\n".join(g["lines"])
+        if g["parsed"] is None:
+            n_rejected += 1
+            with pytest.raises(ValueError):
+                config.load_config(text=text)
+            continue
+        ns = config.load_config(text=text)
+        got = {k: v for k, v in vars(ns).items() if k != "config"}
+        assert got == g["parsed"], rel
+    assert n_rejected >= 1
+    # prefix matching, CLI override, render subset
+    ns = config.load_config(text="N_sample=32\nN_importance = 16\nnear=0.5\ndim_aud=64\n# comment\n", argv=["--perturb", "0"])
+    assert (ns.N_samples, ns.N_importance, ns.near, ns.perturb, ns.chunk) == (32, 16, 0.5, 0.0, 8192)
+    rc = config.to_render_config(ns)
+    assert (rc.N_samples, rc.dim_aud, rc.perturb, rc.dim_latent) == (32, 64, 0.0, 32)
+    with pytest.raises(ValueError):
+        config.load_config(text="no_such_flag=1\n")
+
+
+def test_checkpoint_round_trip_and_adnerf_warm_start(idn, tmp_path):
+    from idealnerf_amd import checkpoint, train as T_
+    from idealnerf_amd.audio_exp_nerf import Network
+    torch.manual_seed(0)
+    net = Network(32, 32, 100.0, 0.3, 0.9, 512, None, 64, 128)
+    lat = torch.randn(5, 32, requires_grad=True)
+    opt = T_.make_optimizer(net, lat)
+    run = tmp_path / "logs" / "exp"
+    for step in (5000, 10000, 900):
+        checkpoint.save_checkpoint(str(run / f"head_{step}.tar"), net, opt, lat, step)
+    assert checkpoint.latest_checkpoint(str(run)).endswith("head_10000.tar")  # natural, not lexical, order
+    assert checkpoint.latest_checkpoint(str(tmp_path / "nope")) is None
+    ck = torch.load(str(run / "head_900.tar"), weights_only=False)
+    assert set(ck) == {"global_step", "model_state_dict", "optimizer", "latent_codes"}
+    net2 = Network(32, 32, 100.0, 0.3, 0.9, 512, None, 64, 128)
+    step, lat2 = checkpoint.load_checkpoint(str(run / "head_10000.tar"), net2, T_.make_optimizer(net2, torch.zeros(5, 32, requires_grad=True)))
+    assert step == 10000 and torch.equal(lat2, lat.data)
+    for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # AD-NeRF checkpoint: audio only network (input widths 127 / 383 / 283), first/skip/view layers dropped
+    ad = idn.FaceNeRF(dim_aud=64, dim_latent=0, dim_expr=0)
+    ft = {"network_fn_state_dict": ad.state_dict(), "network_fine_state_dict": ad.state_dict(),
+          "network_audnet_state_dict": net.aud_net.state_dict(), "network_audattnet_state_dict": net.aud_att_net.state_dict()}
+    net3 = Network(32, 32, 100.0, 0.3, 0.9, 512, None, 64, 128)
+    before = net3.face_nerf_coarse.pts_linears[0].weight.clone()
+    checkpoint.load_adnerf_finetune(ft, net3)
+    assert torch.equal(net3.face_nerf_coarse.pts_linears[3].weight, ad.pts_linears[3].weight)
+    assert torch.equal(net3.face_nerf_coarse.pts_linears[0].weight, before)  # width differs: kept as initialised
