@@ -103,6 +103,8 @@ def query_points_fwd(packed, folded, pts, viewdirs, precision=IDN_PREC_F32) -> t
 
 def frame_rays(c2w, H, W, focal, near, far, row0=0, nrows=None, cx=None, cy=None, device="cuda") -> torch.Tensor:
     lib = _lib.load()
+    if torch.device(device).type != "cuda":
+        raise IdealNerfError(f"frame_rays renders on the GPU (got device {device}); the HIP path has no CPU fallback")
     nrows = H - row0 if nrows is None else nrows
     m = (C.c_float * 12)(*[float(v) for v in c2w[:3, :4].reshape(-1).tolist()])
     out = torch.empty((nrows * W, _lib.RAY_FLOATS), dtype=torch.float32, device=device)

@@ -311,6 +311,32 @@ def main():
     finally:
         aen.raw2outputs, aen.sample_pdf = real_r2o, real_sp
 
+    # ---- L3: the region-weighted ray sampler (GetData.sample_rays, audio_exp_nerf.py:134-195) ------
+    os.makedirs(aen.args.vis_path, exist_ok=True)
+    open(os.path.join(aen.args.vis_path, "torso.jpg"), "a").close()   # skips the debug image write
+    Hs = Ws = 96
+    ds = object.__new__(aen.GetData)
+    ds.H, ds.W, ds.focal, ds.cx, ds.cy = Hs, Ws, 256.0, 48.0, 48.0
+    ds.args = types.SimpleNamespace(N_rand=96, sample_rate=0.95)
+    aen.args.mouth_rays, aen.args.torso_rays = 16, 8
+    pose = syn["c2w"].numpy().astype(np.float64)
+    rect = np.array([10, 8, 70, 80], dtype=np.int32)
+    lms = rs.uniform(8, 88, size=(68, 2))
+    lms[48:] = rs.uniform(42, 54, size=(20, 2))
+    parse = np.zeros((Hs, Ws, 3), dtype=np.uint8)
+    parse[76:, 6:90] = (255, 0, 0)          # torso label
+    parse[:6] = (0, 0, 255)
+    target = f32(rs.uniform(0, 1, size=(Hs, Ws, 3)))
+    bcimg = torch.from_numpy(rs.uniform(0, 1, size=(Hs, Ws, 3)))   # float64 like imread()/255.0
+    np.random.seed(7)
+    with torch.no_grad():
+        brays, tgt_s, bc_s = ds.sample_rays(pose[:3, :4], rect, target, bcimg, lms, parse.copy())
+    np.savez_compressed(os.path.join(HERE, "sample_rays.npz"), pose=pose[:3, :4], rect=rect, landmark=lms, parse=parse,
+                        target=target.numpy(), bc=bcimg.numpy(), batch_rays=brays.numpy(), target_s=tgt_s.numpy(),
+                        bc_s=bc_s.numpy(), focal=256.0, cx=48.0, cy=48.0, N_rand=96, mouth_rays=16, torso_rays=8,
+                        sample_rate=0.95, seed=7)
+    aen.args.mouth_rays, aen.args.torso_rays = 0, 0
+
     # ---- L4: config files through the reference's own flag parser -------------------------
     # (configargparse is absent; it turns `key = value` lines into `--key value` arguments, which is
     # what is fed to the reference's argparse-based parser here.)  Stored: the resolved values, or the

@@ -800,3 +800,18 @@ def test_bf16x3_module_precision_switch(idn, dev, golden):
         o16 = net(*args)
     assert rel_err(o32, g["c235_out"]) < 1e-5 and rel_err(o16, g["c235_out"]) < 5e-5
     assert not torch.equal(o32, o16)
+
+
+def test_dataset_sample_rays_golden(idn, dev, golden):
+    """GetData.sample_rays on the device against the reference run with the same numpy seed."""
+    from idealnerf_amd.dataset import sample_rays
+    g = golden("sample_rays")
+    H, W = g["parse"].shape[:2]
+    np.random.seed(int(g["seed"]))
+    br, ts, bs = sample_rays(g["pose"], g["rect"], T(g["target"]).to(dev), T(g["bc"]).to(dev), g["landmark"], g["parse"],
+                             H, W, float(g["focal"]), float(g["cx"]), float(g["cy"]), int(g["N_rand"]),
+                             int(g["mouth_rays"]), int(g["torso_rays"]), float(g["sample_rate"]), dev)
+    assert br.shape == (2, 96, 3)
+    assert rel_err(br, g["batch_rays"]) < 1e-6
+    np.testing.assert_array_equal(ts.cpu().numpy(), g["target_s"])
+    np.testing.assert_array_equal(bs.cpu().numpy(), g["bc_s"])
