@@ -124,9 +124,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default=os.environ.get("IDN_PRECISION", "bf16x3"),
-                    help="arithmetic of the MLP contraction; both meet the 1e-4 RGB parity bar "
-                         "(tests/test_hip_parity.py), bf16x3 is 3.4x faster and the default")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default=os.environ.get("IDN_PRECISION", "bf16x3"),
+                    help="arithmetic of the MLP contraction; f32 and bf16x3 meet the 1e-4 RGB parity bar "
+                         "(tests/test_hip_parity.py), bf16x3 is 3.4x faster and the default; bf16 (plain, ~1e-2) "
+                         "only meets BASELINE config 5's PSNR criterion and is never the headline number")
     ap.add_argument("--workload", choices=["frame", "train"], default="frame",
                     help="frame = BASELINE configs[1] (default, the headline metric); train = configs[2] train step")
     args = ap.parse_args()
@@ -212,15 +213,16 @@ def main():
         value = samples / dt
         ach = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12 if k_ms.value > 0 else None
         # a bf16x3 kernel issues three bf16 MFMAs per algorithmic product: it is priced against peak / 3
-        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
-        kname = ("idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)" if args.precision == "f32" else
-                 "idn::mlp_bf16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 bf16 MFMAs per product)")
+        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.precision]
+        kname = {"f32": "idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)",
+                 "bf16x3": "idn::mlp_bf16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 bf16 MFMAs per product)",
+                 "bf16": "idn::mlp_bf16_kernel<kModeRays> (fused PE + FaceNeRF MLP, plain bf16 MFMA)"}[args.precision]
         if args.precision != "f32":
             traffic = None
         res = {
             "metric": "ray-samples/sec (64+128 pts, 512x512), whole job", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3 (fp32 in/out, fp32 accumulate)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)"}[args.precision], "data": "synthetic",
             "per_gpu": value / world, "rays_per_s": value / (S + S + Ni),
             "config": {"workload": f"BASELINE configs[1]: May HeadNeRF {H}x{W} full-frame render, N_sample=64 "
                                    "N_importance=128, dim_aud=64 dim_expr=76 latent=32, perturb=0",

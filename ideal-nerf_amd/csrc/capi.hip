@@ -16,8 +16,8 @@ int fail(int code, const char* fmt, ...) {
 }
 
 static int check_precision(int precision) {
-    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3) return IDN_OK;
-    return fail(IDN_EUNSUPPORTED, "precision %d is not built into this library (IDN_PREC_F32, IDN_PREC_BF16X3)", precision);
+    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3 || precision == IDN_PREC_BF16) return IDN_OK;
+    return fail(IDN_EUNSUPPORTED, "precision %d is unknown (IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16)", precision);
 }
 static int check_precision_f32(int precision) {
     if (precision == IDN_PREC_F32) return IDN_OK;
@@ -29,6 +29,8 @@ int launch_mlp(int precision, const float* packed, const float* folded, const fl
                hipStream_t s) {
     if (precision == IDN_PREC_BF16X3)
         return launch_mlp_bf16x3(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
+    if (precision == IDN_PREC_BF16)
+        return launch_mlp_bf16(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
     return launch_mlp_f32(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
 }
 
@@ -78,8 +80,10 @@ int idealnerf_version(void) { return 1; }
 const char* idealnerf_last_error(void) { return g_err; }
 
 size_t idealnerf_packed_weight_floats(int precision) {
-    // both built streams spend 4 bytes per weight (fp32, or bf16 hi + bf16 lo)
-    return (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3) ? (size_t)kStreamFrags * kFragFloats : 0;
+    // 4 bytes per weight (fp32, or bf16 hi + bf16 lo); 2 for the plain-bf16 stream
+    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3) return (size_t)kStreamFrags * kFragFloats;
+    if (precision == IDN_PREC_BF16) return (size_t)kPlainStreamFrags * kFragFloats;
+    return 0;
 }
 size_t idealnerf_folded_bias_floats(void) { return kBiasFloats; }
 
@@ -88,6 +92,7 @@ int idealnerf_pack_weights(const idn_facenerf_params* p, int precision, float* p
     if (int e = check_precision(precision)) return e;
     if (!packed) return fail(IDN_EINVAL, "packed is NULL");
     if (precision == IDN_PREC_BF16X3) return launch_pack_bf16x3(*p, packed, (hipStream_t)stream);
+    if (precision == IDN_PREC_BF16) return launch_pack_bf16(*p, packed, (hipStream_t)stream);
     return launch_pack_f32(*p, packed, (hipStream_t)stream);
 }
 

@@ -57,6 +57,19 @@ static_assert(kUsedFrags == 2244, "layer table changed");
 static_assert(kNumSlices % kRingSlots == 0, "slot of a slice must be static across passes");
 static_assert(kRingFrags == 128, "FragReader addresses the ring as two 64-fragment halves");
 
+// Plain-bf16 stream (IDN_PREC_BF16): weights as one bf16 each, one fragment per 16-channel
+// k-step, so every layer has half the fragments of the 4-byte streams above.
+constexpr int plain_f0(int l) {
+    int f = 0;
+    for (int i = 0; i < l; ++i) f += kLayerNT[i] * (kLayerKG[i] / 2);
+    return f;
+}
+constexpr int kPlainUsedFrags = plain_f0(kNumLayers);                              // 1122
+constexpr int kPlainNumSlices =
+    ((kPlainUsedFrags + kSliceFrags - 1) / kSliceFrags + kRingSlots - 1) / kRingSlots * kRingSlots;  // 18
+constexpr int kPlainStreamFrags = kPlainNumSlices * kSliceFrags;                   // 1152
+static_assert(kPlainUsedFrags == 1122 && kPlainUsedFrags % 2 == 0, "plain stream table changed");
+
 // Folded bias block: one float per output channel, natural channel order
 // (accumulator register 4q+j of tile t, lane half h <-> channel 32 t + 8 q + 4 h + j).
 constexpr int bias_off(int l) {
@@ -115,6 +128,9 @@ struct ProfScope {
 // ---------------------------------------------------------------------------
 int launch_pack_f32(const idn_facenerf_params& p, float* packed, hipStream_t s);
 int launch_pack_bf16x3(const idn_facenerf_params& p, float* packed, hipStream_t s);
+int launch_pack_bf16(const idn_facenerf_params& p, float* packed, hipStream_t s);
+int launch_mlp_bf16(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
+                    const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
 int launch_mlp_bf16x3(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
                       const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
 // precision dispatch for the inference forward

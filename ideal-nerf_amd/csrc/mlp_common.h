@@ -71,6 +71,7 @@ struct WStream {
     const char* gbase;  // stream start + this lane's 16-byte column
     const char* gnext;  // same, for the slice currently being fetched
     int next_slice;
+    int num_slices;     // slices in this stream (kNumSlices, or kPlainNumSlices for the plain-bf16 stream)
     char* ring_wave;    // ring + wave * 1 KiB (wave-uniform LDS destination base)
 #ifdef IDN_DIAG_NOSTREAM
     bool pass_done = true;  // set false to drop all prefetch pieces after the prologue
@@ -78,7 +79,7 @@ struct WStream {
 
     __device__ __forceinline__ void advance() {
         gnext += kSliceBytes;
-        if (++next_slice == kNumSlices) {
+        if (++next_slice == num_slices) {
             next_slice = 0;
             gnext = gbase;
         }
@@ -158,10 +159,10 @@ struct FragReader {
 // End of a pass: walk the unused tail of the stream (padding) without reading it, so that the
 // barriers and prefetch pieces scheduled on those positions still happen and the next pass
 // finds its first kAhead slices in flight.
-template <int F_END>
+template <int F_END, int STREAM_FRAGS = kStreamFrags>
 __device__ __forceinline__ void finish_pass(WStream& ws) {
     static_assert(F_END % 2 == 0, "pairs");
-    static_for<(kStreamFrags - F_END) / 2>([&](auto I) {
+    static_for<(STREAM_FRAGS - F_END) / 2>([&](auto I) {
         constexpr int f = F_END + 2 * decltype(I)::value;
         if constexpr (f % kSliceFrags == 0) ws.open_slice();
         ws.template step_piece<f>();

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
     ws.gbase = reinterpret_cast<const char*>(a.wstream) + tid * 16;
     ws.gnext = ws.gbase;
     ws.next_slice = 0;
+    ws.num_slices = kNumSlices;
     ws.ring_wave = ring + wave * kFragBytes;
     ws.prologue();
 

@@ -85,7 +85,45 @@ __global__ void pack_bf16x3_kernel(PackDesc d, uint4* out) {
     out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// plain-bf16 stream: one fragment per (tile, k-step): 8 bf16 per lane, same channel order
+__global__ void pack_bf16_kernel(PackDesc d, uint4* out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= kPlainStreamFrags * 64) return;
+    const int f = gid >> 6, lane = gid & 63;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (f < kPlainUsedFrags) {
+        int l = 0;
+        while (l + 1 < kNumLayers && f >= d.L[l + 1].f0 / 2) ++l;
+        const PackLayer& L = d.L[l];
+        const int rel = f - L.f0 / 2, ksn = L.kg / 2;
+        const int t = rel / ksn, ks = rel - t * ksn;
+        const int n = 32 * t + (lane & 31), h = lane >> 5;
+        const int ks0 = L.kg0 >> 1;
+        const int src = ks < ks0 ? 0 : 1;
+        const int kbase = 16 * (src ? ks - ks0 : ks) + 4 * h;
+        for (int j = 0; j < 8; ++j) {
+            const int k = kbase + (j & 3) + 8 * (j >> 2);
+            float v = 0.f;
+            if (k < L.kvalid[src]) {
+                if (n < L.rows) v = L.w[(long)n * L.ld + L.col0[src] + k];
+                else if (L.w_extra && n == L.extra_at && src == 0) v = L.w_extra[k];
+            }
+            w[j >> 1] |= bf16_rne(v) << (16 * (j & 1));
+        }
+    }
+    out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 static void fill_pack_desc(const idn_facenerf_params& p, PackDesc& d);
+
+int launch_pack_bf16(const idn_facenerf_params& p, float* packed, hipStream_t s) {
+    PackDesc d;
+    fill_pack_desc(p, d);
+    const int total = kPlainStreamFrags * 64;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d, reinterpret_cast<uint4*>(packed));
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
 
 int launch_pack_bf16x3(const idn_facenerf_params& p, float* packed, hipStream_t s) {
     PackDesc d;

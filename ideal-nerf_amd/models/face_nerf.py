@@ -10,15 +10,16 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .._lib import IDN_PREC_BF16X3, IDN_PREC_F32
+from .._lib import IDN_PREC_BF16, IDN_PREC_BF16X3, IDN_PREC_F32
 
-PRECISIONS = {"f32": IDN_PREC_F32, "bf16x3": IDN_PREC_BF16X3}
+PRECISIONS = {"f32": IDN_PREC_F32, "bf16x3": IDN_PREC_BF16X3, "bf16": IDN_PREC_BF16}
 _default_precision = ["f32"]
 
 
 def set_default_precision(name: str):
     """Arithmetic of the MLP contraction for modules created afterwards: "f32" (exact fp32
-    MFMA) or "bf16x3" (three bf16 MFMAs per product, ~1.5e-5 relative on the output)."""
+    MFMA), "bf16x3" (three bf16 MFMAs per product, ~1.5e-5 relative on the output) or "bf16"
+    (plain bf16, ~1e-2: PSNR-judged rendering only, BASELINE config 5)."""
     if name not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     _default_precision[0] = name
