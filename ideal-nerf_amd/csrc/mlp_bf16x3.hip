@@ -152,12 +152,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
     Diag dg;
     WStream ws;
     ws.dg = &dg;
-    ws.gbase = reinterpret_cast<const char*>(a.wstream) + tid * 16;
-    ws.gnext = ws.gbase;
-    ws.next_slice = 0;
-    ws.num_slices = kNumSlices;
-    ws.ring_wave = ring + wave * kFragBytes;
-    ws.prologue();
+    ws.init(a.wstream, kNumSlices, ring, tid, wave);
 
     FragReader fr;
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
@@ -385,12 +380,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs a) {
     Diag dg;
     WStream ws;
     ws.dg = &dg;
-    ws.gbase = reinterpret_cast<const char*>(a.wstream) + tid * 16;
-    ws.gnext = ws.gbase;
-    ws.next_slice = 0;
-    ws.num_slices = kPlainNumSlices;
-    ws.ring_wave = ring + wave * kFragBytes;
-    ws.prologue();
+    ws.init(a.wstream, kPlainNumSlices, ring, tid, wave);
     FragReader fr;
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
     fr.addr1 = fr.addr0 + 64 * kFragBytes;

@@ -62,14 +62,25 @@ struct Diag {};
 // vector-memory operations of the wave only make the counted wait stricter.
 // ---------------------------------------------------------------------------
 constexpr int kPieces = kSliceFrags / 4;                    // pieces per slice
+#ifndef IDN_PIECES_PER_STEP
+#define IDN_PIECES_PER_STEP 1
+#endif
+constexpr int kPiecesPerStep = IDN_PIECES_PER_STEP;         // pieces issued per fragment-pair step
+static_assert(kPieces % kPiecesPerStep == 0, "a slice is a whole number of steps");
 constexpr int kAhead = kRingSlots - 1;                      // slices in flight ahead of the consumer
 constexpr int kVmcntOpen = (kAhead - 1) * kPieces;          // younger pieces allowed in flight at a barrier
 static_assert(kVmcntOpen == 0 || kVmcntOpen == 8 || kVmcntOpen == 16, "add the s_waitcnt literal below");
 
 struct WStream {
     Diag* dg;
-    const char* gbase;  // stream start + this lane's 16-byte column
-    const char* gnext;  // same, for the slice currently being fetched
+    // Pieces are buffer_load_dwordx4 ... lds: descriptor (4 SGPRs) + one constant VGPR (lane * 16) +
+    // a scalar stream offset.  Measured beside an MFMA chain (tools/glds_ubench.hip) a piece in
+    // this form costs the issuing wave ~1.5 cycles against ~8 for global_load_lds with per-lane
+    // 64-bit pointers, and the clock holds ~10 % higher.  The descriptor's num_records bounds
+    // every piece to the stream (an out-of-range piece reads zeros instead of faulting).
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff;      // this lane's 16-byte column inside a piece
+    uint32_t soff;      // byte offset of the slice currently being fetched (wave-uniform)
     int next_slice;
     int num_slices;     // slices in this stream (kNumSlices, or kPlainNumSlices for the plain-bf16 stream)
     char* ring_wave;    // ring + wave * 1 KiB (wave-uniform LDS destination base)
@@ -77,11 +88,20 @@ struct WStream {
     bool pass_done = true;  // set false to drop all prefetch pieces after the prologue
 #endif
 
+    __device__ __forceinline__ void init(const float* stream, int slices, char* ring, int tid, int wave) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, slices * kSliceBytes, 0x00020000);  // raw, untyped
+        voff = tid * 16;
+        soff = 0;
+        next_slice = 0;
+        num_slices = slices;
+        ring_wave = ring + wave * kFragBytes;
+        prologue();
+    }
     __device__ __forceinline__ void advance() {
-        gnext += kSliceBytes;
+        soff += kSliceBytes;
         if (++next_slice == num_slices) {
             next_slice = 0;
-            gnext = gbase;
+            soff = 0;
         }
     }
     template <int SLOT, int J>
@@ -89,8 +109,8 @@ struct WStream {
 #ifdef IDN_DIAG_NOSTREAM  // timing-only experiment: what does the weight stream cost? (outputs are garbage)
         if (pass_done)
 #endif
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gnext + J * 4096),
-                                         LDS_PTR(ring_wave + SLOT * kSliceBytes + J * 4096), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(ring_wave + SLOT * kSliceBytes + J * 4096), 16, voff,
+                                                 soff + J * 4096, 0, 0);
         if constexpr (J == kPieces - 1) advance();
     }
     template <int SLOT, int J0>
@@ -99,6 +119,9 @@ struct WStream {
     }
     // kernel start: slices 0 .. kAhead-1 into slots 0 .. kAhead-1
     __device__ __forceinline__ void prologue() {
+#ifdef IDN_STAGGER  // experiment: spread the workgroups of an XCD over one slice period
+        for (int i = (blockIdx.x >> 3) & 31; i > 0; --i) __builtin_amdgcn_s_sleep(IDN_STAGGER);
+#endif
         static_for<kAhead>([&](auto S_) { issue_rest<decltype(S_)::value, 0>(); });
 #ifdef IDN_DIAG_NOSTREAM
         pass_done = false;
@@ -109,7 +132,11 @@ struct WStream {
     // wave is done reading the slot the next pieces will overwrite.
     __device__ __forceinline__ void open_slice() {
         DIAG_BEGIN(*dg);
+#ifdef IDN_DIAG_NOWAIT  // timing-only experiment: pieces are issued but never waited for (outputs are garbage)
+        if constexpr (false) {}
+#else
         if constexpr (kVmcntOpen == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         else if constexpr (kVmcntOpen == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -121,7 +148,8 @@ struct WStream {
     __device__ __forceinline__ void step_piece() {
         constexpr int jpos = (F % kSliceFrags) / 2;
         constexpr int slot = (F / kSliceFrags + kAhead) % kRingSlots;
-        if constexpr (jpos < kPieces) issue_piece<slot, jpos>();
+        if constexpr (jpos * kPiecesPerStep < kPieces)
+            static_for<kPiecesPerStep>([&](auto I) { issue_piece<slot, jpos * kPiecesPerStep + decltype(I)::value>(); });
     }
 };
 
@@ -189,7 +217,18 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[NT], const float* bias_h
     static_for<NT>([&](auto T) { bias_tile(acc[decltype(T)::value], bias_half + 32 * decltype(T)::value); });
 }
 
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }  // one v_med3_f32
+// ReLU as exactly one VALU instruction.  Written as asm because every builtin spelling (fmaxf,
+// fmed3) is canonicalised by hipcc into v_max_f32 x,x ; v_max_f32 0,x -- twice the issue slots,
+// in the part of the kernel where VALU issue is what the MFMA chain competes with.
+__device__ __forceinline__ float relu1(float x) {
+#ifdef IDN_RELU_BUILTIN  // A/B arm
+    return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
+#else
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+#endif
+}
 // ReLU, in place, of registers [R0, R0 + CNT) of a tile (clipped to the 16 a tile has)
 template <int R0, int CNT>
 __device__ __forceinline__ void relu_regs(f32x16& tile) {

@@ -1,0 +1,100 @@
+// Microbenchmark: does VALU work co-issue for free beside v_mfma_f32_32x32x16_bf16 on gfx950?
+// One wave per SIMD, every CU busy (so the clock is the one the real kernel sees).
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_bf16_ubench.hip -o tools/mfma_bf16_ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mf(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// KIND: 0 = v_med3_f32 (fp32 ALU), 1 = v_cvt_pk_bf16_f32, 2 = v_and_b32 (integer), 3 = v_mov_b32, 4 = v_fma_f64
+template <int KIND>
+__device__ __forceinline__ void valu(float& x, float y, double& d) {
+    if constexpr (KIND == 0) asm volatile("v_med3_f32 %0, %0, 0, %1" : "+v"(x) : "v"(y));
+    else if constexpr (KIND == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x) : "v"(y));
+    else if constexpr (KIND == 2) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(y));
+    else if constexpr (KIND == 3) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(y));
+    else asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(d));
+}
+
+template <int NV, int KIND, int NACC, int NLDS>
+__global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* cyc, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[16384];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = (float)(i & 7) * 0.01f;
+    __syncthreads();
+    f32x16 acc[2] = {{0}, {0}};
+    f32x4 a = {1.f, 2.f, 3.f, 4.f}, b = {out[lane], out[lane + 64], out[lane + 128], out[lane + 192]}, an = a, an2 = a;
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds + lane * 16;
+    float side[8];
+    double d = out[lane];
+    for (int i = 0; i < 8; ++i) side[i] = out[lane + i];
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if constexpr (NLDS >= 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(an) : "v"(addr), "n"(1024) : "memory");
+            if constexpr (NLDS >= 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(an2) : "v"(addr), "n"(2048) : "memory");
+            if constexpr (NLDS >= 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(NLDS) : "memory");
+            acc[u % NACC] = mf(a, b, acc[u % NACC]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) valu<KIND>(side[v & 7], b.x, d);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NLDS >= 1) a = an;
+            if constexpr (NLDS >= 2) b.y = an2.x;
+        }
+    }
+    const unsigned long long t1 = clock64();
+    float s = (float)d;
+    for (int r = 0; r < 16; ++r) s += acc[0][r] + acc[1][r];
+    for (int i = 0; i < 8; ++i) s += side[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int NV, int KIND, int NACC, int NLDS>
+void run(const char* name, float* out, unsigned long long* cyc, int blocks) {
+    const int iters = 4000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<NV, KIND, NACC, NLDS>), dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<NV, KIND, NACC, NLDS>), dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
+    double avg = 0; for (auto v : h) avg += v; avg /= blocks;
+    const double n = (double)iters * 16;
+    printf("%-52s %7.2f ticks/MFMA  %7.2f ns/MFMA  %7.1f TFLOP/s\n", name, avg / n, ms * 1e6 / n, n * 32768.0 * 4 * blocks / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    int blocks = 256;
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, blocks * 256 * 4 + 1024); hipMemset(out, 0, blocks * 256 * 4 + 1024);
+    hipMalloc(&cyc, blocks * 8);
+    run<0, 0, 1, 0>("dependent chain, no VALU", out, cyc, blocks);
+    run<0, 0, 2, 0>("2 accumulators, no VALU", out, cyc, blocks);
+    run<2, 0, 1, 0>("chain + 2 v_med3_f32 / MFMA", out, cyc, blocks);
+    run<4, 0, 1, 0>("chain + 4 v_med3_f32 / MFMA", out, cyc, blocks);
+    run<6, 0, 1, 0>("chain + 6 v_med3_f32 / MFMA", out, cyc, blocks);
+    run<8, 0, 1, 0>("chain + 8 v_med3_f32 / MFMA", out, cyc, blocks);
+    run<4, 1, 1, 0>("chain + 4 v_cvt_pk_bf16_f32 / MFMA", out, cyc, blocks);
+    run<8, 1, 1, 0>("chain + 8 v_cvt_pk_bf16_f32 / MFMA", out, cyc, blocks);
+    run<4, 2, 1, 0>("chain + 4 v_and_b32 / MFMA", out, cyc, blocks);
+    run<8, 2, 1, 0>("chain + 8 v_and_b32 / MFMA", out, cyc, blocks);
+    run<4, 3, 1, 0>("chain + 4 v_mov_b32 / MFMA", out, cyc, blocks);
+    run<8, 3, 1, 0>("chain + 8 v_mov_b32 / MFMA", out, cyc, blocks);
+    run<2, 4, 1, 0>("chain + 2 v_fma_f64 / MFMA", out, cyc, blocks);
+    run<4, 4, 1, 0>("chain + 4 v_fma_f64 / MFMA", out, cyc, blocks);
+    run<0, 0, 1, 1>("chain + 1 ds_read_b128 / MFMA", out, cyc, blocks);
+    run<0, 0, 1, 2>("chain + 2 ds_read_b128 / MFMA", out, cyc, blocks);
+    run<4, 0, 1, 1>("chain + 1 ds_read_b128 + 4 v_med3 / MFMA", out, cyc, blocks);
+    run<4, 0, 2, 1>("2 acc + 1 ds_read_b128 + 4 v_med3 / MFMA", out, cyc, blocks);
+    return 0;
+}
