@@ -18,7 +18,7 @@ constexpr int kSrcBytes = 2304 * 1024;  // the bf16x3 weight stream's size
 // KIND 0 none | 1 global_load_lds x4, 64-bit per-lane pointer | 2 raw_buffer_load_lds x4, offen (32-bit voffset)
 //      3 raw_buffer_load_lds x4, no VGPR (ADD_TID_ENABLE descriptor) | 4 global_load_dwordx4 into VGPRs (no LDS)
 //      5 global_load_lds x4 saddr form (uniform base + 32-bit lane offset)
-template <int KIND, int NM, int NR = 0, int NV = 0>
+template <int KIND, int NM, int NR = 0, int NV = 0, int PLACE = 0>
 __global__ __launch_bounds__(256, 1) void k(const char* src, float* out, unsigned long long* cyc, int iters) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -39,18 +39,21 @@ __global__ __launch_bounds__(256, 1) void k(const char* src, float* out, unsigne
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             char* dst = ring_wave + ((it * 8 + u) & 15) * 4096;
-            if constexpr (KIND == 1) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gl + pos), LDS_PTR(dst), 16, 0, 0);
-            if constexpr (KIND == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, tid * 16, pos, 0, 0);
-            if constexpr (KIND == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, LDS_PTR(dst), 16, 0, pos + wave * 1024, 0, 0);
-            if constexpr (KIND == 4) {
+            auto piece = [&]() {
+                if constexpr (KIND == 1) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gl + pos), LDS_PTR(dst), 16, 0, 0);
+                if constexpr (KIND == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, tid * 16, pos, 0, 0);
+                if constexpr (KIND == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, LDS_PTR(dst), 16, 0, pos + wave * 1024, 0, 0);
+                if constexpr (KIND == 4) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(gl + pos);
                 asm volatile("" : "+v"(v));
                 sink = v;
-            }
-            if constexpr (KIND == 5) {
+                }
+                if constexpr (KIND == 5) {
                 const char* sb = src + pos;  // uniform
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(sb + (unsigned)(tid * 16)), LDS_PTR(dst), 16, 0, 0);
-            }
+                }
+            };
+            if constexpr (PLACE == 0) piece();
             pos += 4096;
             if (pos >= kSrcBytes) pos = 0;
             // NR fragment reads per step, issued one step ahead of their use (as the MLP kernel does)
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(256, 1) void k(const char* src, float* out, unsigne
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 acc = mf(m & 1 ? a2 : a, b, acc);
+                if (PLACE == m + 1) piece();
 #pragma unroll
                 for (int v = 0; v < NV; ++v) asm volatile("v_med3_f32 %0, %0, 0, %1" : "+v"(side[v & 7]) : "v"(b.x));
             }
@@ -80,15 +84,15 @@ __global__ __launch_bounds__(256, 1) void k(const char* src, float* out, unsigne
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int KIND, int NM, int NR = 0, int NV = 0>
+template <int KIND, int NM, int NR = 0, int NV = 0, int PLACE = 0>
 void run(const char* name, const char* src, float* out, unsigned long long* cyc, int blocks) {
     const int iters = 2000;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<KIND, NM, NR, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipLaunchKernelGGL((k<KIND, NM, NR, NV>), dim3(blocks), dim3(256), 65536, 0, src, out, cyc, iters);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<KIND, NM, NR, NV, PLACE>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL((k<KIND, NM, NR, NV, PLACE>), dim3(blocks), dim3(256), 65536, 0, src, out, cyc, iters);
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<KIND, NM, NR, NV>), dim3(blocks), dim3(256), 65536, 0, src, out, cyc, iters);
+    hipLaunchKernelGGL((k<KIND, NM, NR, NV, PLACE>), dim3(blocks), dim3(256), 65536, 0, src, out, cyc, iters);
     (void)hipEventRecord(e1);
     (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -107,20 +111,18 @@ int main() {
     (void)hipMalloc(&out, blocks * 256 * 4 + 1024); (void)hipMemset(out, 0, blocks * 256 * 4 + 1024);
     (void)hipMalloc(&cyc, blocks * 8);
     (void)hipMalloc(&src, kSrcBytes + 8192); (void)hipMemset(src, 0, kSrcBytes + 8192);
-    run<0, 3>("3 MFMA", src, out, cyc, blocks);
     run<0, 3, 2, 4>("3 MFMA + 2 ds_read + 12 VALU", src, out, cyc, blocks);
-    run<2, 3, 2, 4>("3 MFMA + 2 ds_read + 12 VALU + buffer piece (offen)", src, out, cyc, blocks);
-    run<3, 3, 2, 4>("3 MFMA + 2 ds_read + 12 VALU + buffer piece (ADD_TID)", src, out, cyc, blocks);
-    run<1, 3, 2, 4>("3 MFMA + 2 ds_read + 12 VALU + global piece", src, out, cyc, blocks);
-    run<0, 3, 2, 3>("3 MFMA + 2 ds_read + 9 VALU", src, out, cyc, blocks);
-    run<2, 3, 2, 3>("3 MFMA + 2 ds_read + 9 VALU + buffer piece (offen)", src, out, cyc, blocks);
-    run<3, 3, 2, 3>("3 MFMA + 2 ds_read + 9 VALU + buffer piece (ADD_TID)", src, out, cyc, blocks);
+    run<2, 3, 2, 4, 0>("  + buffer piece at the top of the step", src, out, cyc, blocks);
+    run<2, 3, 2, 4, 1>("  + buffer piece after MFMA 1", src, out, cyc, blocks);
+    run<2, 3, 2, 4, 2>("  + buffer piece after MFMA 2", src, out, cyc, blocks);
+    run<2, 3, 2, 4, 3>("  + buffer piece after MFMA 3 (+VALU)", src, out, cyc, blocks);
     run<0, 3, 2, 2>("3 MFMA + 2 ds_read + 6 VALU", src, out, cyc, blocks);
-    run<2, 3, 2, 2>("3 MFMA + 2 ds_read + 6 VALU + buffer piece (offen)", src, out, cyc, blocks);
-    run<0, 3, 0, 4>("3 MFMA + 12 VALU", src, out, cyc, blocks);
-    run<2, 3, 0, 4>("3 MFMA + 12 VALU + buffer piece (offen)", src, out, cyc, blocks);
-    run<0, 2, 2, 4>("2 MFMA + 2 ds_read + 8 VALU", src, out, cyc, blocks);
-    run<2, 2, 2, 4>("2 MFMA + 2 ds_read + 8 VALU + buffer piece (offen)", src, out, cyc, blocks);
-    run<3, 2, 2, 4>("2 MFMA + 2 ds_read + 8 VALU + buffer piece (ADD_TID)", src, out, cyc, blocks);
+    run<2, 3, 2, 2, 0>("  + buffer piece at the top of the step", src, out, cyc, blocks);
+    run<2, 3, 2, 2, 1>("  + buffer piece after MFMA 1", src, out, cyc, blocks);
+    run<2, 3, 2, 2, 2>("  + buffer piece after MFMA 2", src, out, cyc, blocks);
+    run<0, 2, 2, 3>("2 MFMA + 2 ds_read + 6 VALU", src, out, cyc, blocks);
+    run<2, 2, 2, 3, 0>("  + buffer piece at the top of the step", src, out, cyc, blocks);
+    run<2, 2, 2, 3, 1>("  + buffer piece after MFMA 1", src, out, cyc, blocks);
+    run<2, 2, 2, 3, 2>("  + buffer piece after MFMA 2", src, out, cyc, blocks);
     return 0;
 }
