@@ -57,6 +57,7 @@ PROTOTYPES = {
     "idealnerf_query_points_fwd": (C.c_int, [fp, fp, C.c_int, fp, fp, C.c_int64, C.c_int, fp, fp]),
     "idealnerf_frame_rays": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_int, C.c_int, fp, fp]),
+    "idealnerf_to8b": (C.c_int, [fp, C.c_int64, C.c_int, fp, fp, fp]),
     "idealnerf_coarse_depths": (C.c_int, [fp, fp, fp, C.c_int64, C.c_int, fp, fp]),
     "idealnerf_composite_fwd": (C.c_int, [fp, fp, fp, fp, C.c_int64, C.c_int, C.POINTER(CompositeOut), fp]),
     "idealnerf_sample_pdf_fwd": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp]),

@@ -152,6 +152,13 @@ int idealnerf_coarse_depths(const float* rays, const float* t_vals, const float*
     return launch_coarse_depths(rays, t_vals, t_rand, n_rays, n_samples, z, (hipStream_t)stream);
 }
 
+int idealnerf_to8b(const float* rgb, int64_t n_pixels, int swap_rb, uint8_t* out, int* nonfinite_flag, void* stream) {
+    if (n_pixels < 0) return fail(IDN_EINVAL, "n_pixels < 0");
+    if (n_pixels == 0) return IDN_OK;
+    if (!rgb || !out) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_to8b(rgb, n_pixels, swap_rb, out, nonfinite_flag, (hipStream_t)stream);
+}
+
 int idealnerf_composite_fwd(const float* raw, const float* z, const float* rays, const float* bc_rgb,
                             int64_t n_rays, int n_samples, const idn_composite_out* out, void* stream) {
     if (n_rays < 0) return fail(IDN_EINVAL, "n_rays < 0");

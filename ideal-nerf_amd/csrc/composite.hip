@@ -127,6 +127,35 @@ int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_
 }
 
 // ---------------------------------------------------------------------------
+// frame tail: to8b (NeRFs/HeadNeRF/helper.py:154, `(255 * np.clip(x, 0, 1)).astype(np.uint8)`) and
+// the NaN/Inf scan of the render dict (audio_exp_nerf.py:367-369) as ONE device-side flag.
+// 255 * clip(x) is an fp32 product, astype truncates.  A NaN pixel is written as 0 and flagged.
+// ---------------------------------------------------------------------------
+__global__ void to8b_kernel(const float* __restrict__ rgb, long n_values, int swap_rb, unsigned char* __restrict__ out,
+                            int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n_values) {
+        const float x = rgb[i];
+        bad = !(fabsf(x) <= 3.402823466e+38f);  // NaN or +-Inf
+        float c = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+        if (x != x) c = 0.0f;
+        const long px = i / 3;
+        const int ch = (int)(i - px * 3);
+        out[px * 3 + (swap_rb ? 2 - ch : ch)] = (unsigned char)(int)(255.0f * c);
+    }
+    if (flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+int launch_to8b(const float* rgb, int64_t n_pixels, int swap_rb, unsigned char* out, int* flag, hipStream_t s) {
+    const long n = (long)n_pixels * 3;
+    if (n <= 0) return IDN_OK;
+    hipLaunchKernelGGL(to8b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rgb, n, swap_rb, out, flag);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+// ---------------------------------------------------------------------------
 // a6: raw2outputs (NeRFs/HeadNeRF/train/baseline.py:325-375; rgb_fg: TorsoNeRF/run_nerf.py:757)
 // Lane l owns samples l*SPL .. l*SPL+SPL-1 (contiguous, so a ray's prefix product is a
 // lane-local product followed by one wave scan).

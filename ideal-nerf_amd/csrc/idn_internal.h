@@ -147,6 +147,7 @@ int launch_mlp_f32(const float* packed, const float* folded, const float* x, con
 
 int launch_frame_rays(const float* c2w, int H, int W, float focal, float cx, float cy, float near_, float far_,
                       int row0, int nrows, float* rays_out, hipStream_t s);
+int launch_to8b(const float* rgb, int64_t n_pixels, int swap_rb, unsigned char* out, int* flag, hipStream_t s);
 int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays, int S,
                          float* z, hipStream_t s);
 int launch_composite(const float* raw, const float* z, const float* rays, const float* bc, int64_t n_rays, int S,

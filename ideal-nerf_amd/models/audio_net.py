@@ -54,3 +54,30 @@ class DeepSpeechAudNet(nn.Module):
     def forward(self, x):  # x: [n, 16, 29]
         x = self.encoder_fc(x.permute(0, 2, 1)).squeeze(-1)
         return x.squeeze()
+
+
+def clip_audio_features(aud_net: AudioNet, aud_att_net: AudioAttNet, auds: torch.Tensor, smo_size: int = 8) -> torch.Tensor:
+    """Smoothed audio feature of EVERY frame of a clip in one batched pass: [F, 16, 29] -> [F, dim_aud].
+
+    The reference walks the clip frame by frame (NeRFs/TorsoNeRF/test_torso.py:478-498; the same
+    window logic per call in audio_exp_nerf.py:246-262): slice a window of `smo_size` frames,
+    zero-pad the RAW DeepSpeech window at the clip ends, run AudioNet on the window and AudioAttNet
+    on its output.  AudioNet treats frames independently, so it is run once over the clip (plus
+    once on an all-zero frame, whose feature is what a padded slot becomes -- not zero: the
+    convolutions have biases), windows are gathered from that table, and AudioAttNet's
+    convolutions/linear run batched over the F windows.
+    """
+    F = auds.shape[0]
+    half = int(smo_size / 2)
+    if F < smo_size:  # the reference's zeros_like(win)[:pad] clips the padding to the window length
+        raise ValueError(f"clip of {F} frames is shorter than the smoothing window ({smo_size})")
+    feats = aud_net(auds).reshape(F, -1)
+    pad = aud_net(torch.zeros_like(auds[:1])).reshape(1, -1)
+    table = torch.cat([feats, pad], dim=0)
+    idx = torch.arange(F, device=auds.device)[:, None] + torch.arange(-half, half, device=auds.device)[None, :]
+    idx = torch.where((idx >= 0) & (idx < F), idx, torch.full_like(idx, F))
+    win = table[idx]                                                  # [F, smo, dim_aud]
+    y = win[..., :aud_att_net.dim_aud].permute(0, 2, 1)               # [F, dim_att, smo]
+    y = aud_att_net.attentionConvNet(y)                               # [F, 1, smo]
+    y = aud_att_net.attentionNet(y.reshape(F, aud_att_net.seq_len))   # softmax over the window
+    return torch.sum(y.unsqueeze(-1) * win, dim=1)

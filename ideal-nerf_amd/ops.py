@@ -114,6 +114,20 @@ def frame_rays(c2w, H, W, focal, near, far, row0=0, nrows=None, cx=None, cy=None
     return out
 
 
+def to8b(rgb, swap_rb=False, nonfinite_flag=None) -> torch.Tensor:
+    """helper.py:154 on the device: [..., 3] fp32 -> [..., 3] uint8.  `nonfinite_flag` (int32[1] on
+    the device) is OR-ed with 1 when the frame holds a NaN/Inf."""
+    lib = _lib.load()
+    if rgb.shape[-1] != 3:
+        raise IdealNerfError(f"to8b expects [..., 3], got {tuple(rgb.shape)}")
+    out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+    if nonfinite_flag is not None and (nonfinite_flag.dtype != torch.int32 or not nonfinite_flag.is_cuda):
+        raise IdealNerfError("nonfinite_flag must be an int32 device tensor")
+    check(lib.idealnerf_to8b(_ptr(rgb, "rgb"), rgb.numel() // 3, int(bool(swap_rb)), out.data_ptr(),
+                             nonfinite_flag.data_ptr() if nonfinite_flag is not None else None, _stream()))
+    return out
+
+
 def coarse_depths(rays, t_vals, t_rand=None) -> torch.Tensor:
     lib = _lib.load()
     n, S = rays.shape[0], t_vals.shape[0]

@@ -253,6 +253,16 @@ int idealnerf_pass_bwd(const idn_facenerf_params* p, const idn_facenerf_grads* g
                        float* d_latent, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Frame tail.  to8b = `(255 * np.clip(x, 0, 1)).astype(np.uint8)` (NeRFs/HeadNeRF/helper.py:154) on
+ * the device: rgb [n_pixels,3] fp32 -> out [n_pixels,3] u8, bit-identical to numpy for finite input;
+ * swap_rb != 0 writes the channels in reverse order (the cv2.cvtColor the reference leaves
+ * commented out, test/eval_aud_exp_nerf.py:490).  nonfinite_flag (device int, may be NULL) is
+ * OR-ed with 1 if any input value is NaN/Inf: one flag per frame replaces the reference's
+ * per-chunk isnan/isinf host syncs (train/audio_exp_nerf.py:367-369); such a value is written as 0.
+ */
+int idealnerf_to8b(const float* rgb, int64_t n_pixels, int swap_rb, uint8_t* out, int* nonfinite_flag, void* stream);
+
+/*
  * Measurement aid (no reference counterpart): between begin and end, every launch of
  * the fused PE+MLP kernel is bracketed by HIP events on its own stream.  end()
  * synchronises those events and returns the summed kernel time, the number of launches

@@ -371,5 +371,84 @@ def main():
             print(f"{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:8.1f} KiB")
 
 
+def agg_state(seed):
+    """FaceNeRFAgg weights (models/face_nerf_agg.py:28-48 shapes, dim_agg=64, aud 64, expr 76, latent 32):
+    Xavier-uniform from numpy RandomState(seed) in state_dict order, bias 0.01.  Rebuilt identically by
+    the tests, so the fixture stores no weights."""
+    import collections
+    shapes = collections.OrderedDict()
+    shapes["agg_linears.0"] = (64, 140)
+    shapes["agg_linears.1"] = (64, 64)
+    c_all = 63 + 64 + 32
+    for i in range(8):
+        shapes[f"pts_linears.{i}"] = (256, c_all if i == 0 else (256 + c_all if i == 5 else 256))
+    shapes["views_linears.0"] = (128, 27 + 256 + 64)
+    shapes["views_linears.1"] = (128, 128)
+    shapes["views_linears.2"] = (128, 128)
+    shapes["feature_linear"] = (256, 256)
+    shapes["alpha_linear"] = (1, 256)
+    shapes["rgb_linear"] = (3, 128)
+    rs = np.random.RandomState(seed)
+    sd = collections.OrderedDict()
+    for k, (o, i) in shapes.items():
+        bound = float(np.sqrt(6.0 / (o + i)))
+        sd[k + ".weight"] = torch.from_numpy(rs.uniform(-bound, bound, size=(o, i)).astype(np.float32))
+        sd[k + ".bias"] = torch.full((o,), 0.01, dtype=torch.float32)
+    return sd
+
+
+def golden_agg():
+    """`python make_golden.py agg`: FaceNeRFAgg and the clip-level audio loop of
+    NeRFs/TorsoNeRF/test_torso.py:478-498, written next to the other fixtures without touching them."""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    torch.set_num_threads(8)
+    from models.face_nerf_agg import FaceNeRFAgg
+    from models.audio_net import AudioNet, AudioAttNet
+    rs = np.random.RandomState(4321)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    net = FaceNeRFAgg(D=8, W=256, input_ch=63, input_ch_views=27, dim_agg=64, dim_aud=64, dim_expr=76, dim_latent=32,
+                      skips=[4])
+    sd = agg_state(21)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    x = f32(rs.uniform(-1.0, 1.0, size=(384, 90)))
+    aud, expr, lat = f32(rs.standard_normal(64)), f32(rs.standard_normal(76)), f32(rs.standard_normal(32))
+    with torch.no_grad():
+        y = net(x, aud, expr, lat)
+    np.savez(os.path.join(HERE, "facenerf_agg.npz"), x=x.numpy(), aud=aud.numpy(), expr=expr.numpy(), latent=lat.numpy(),
+             out=y.numpy(), seed=21)
+
+    # clip-level audio features: the literal loop of test_torso.py:478-498 (smo_size 8)
+    torch.manual_seed(77)
+    aud_net, att_net = AudioNet(64, 16), AudioAttNet()
+    auds = f32(rs.standard_normal((21, 16, 29)))
+    half, F = 4, auds.shape[0]
+    outs = []
+    with torch.no_grad():
+        for i in range(F):
+            left_i, right_i, pad_left, pad_right = i - half, i + half, 0, 0
+            if left_i < 0:
+                pad_left, left_i = -left_i, 0
+            if right_i > F:
+                pad_right, right_i = right_i - F, F
+            win = auds[left_i:right_i]
+            if pad_left > 0:
+                win = torch.cat((torch.zeros_like(win)[:pad_left], win), dim=0)
+            if pad_right > 0:
+                win = torch.cat((win, torch.zeros_like(win)[:pad_right]), dim=0)
+            outs.append(att_net(aud_net(win)))
+    fx = {"auds": auds.numpy(), "out": torch.stack(outs, 0).numpy()}
+    for k, v in aud_net.state_dict().items():
+        fx["audnet." + k] = v.numpy()
+    for k, v in att_net.state_dict().items():
+        fx["attnet." + k] = v.numpy()
+    np.savez(os.path.join(HERE, "audio_clip.npz"), **fx)
+    print("wrote facenerf_agg.npz, audio_clip.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "agg":
+        golden_agg()
+    else:
+        main()

@@ -340,3 +340,51 @@ def test_dataset_reader_on_synthetic_directory(idn, tmp_path):
     assert sel.shape == (64, 2) and len({tuple(r) for r in sel[:49]}) == 49       # no replacement inside a region
     with pytest.raises(idn._lib.IdealNerfError):
         ds[0]  # ray generation is a device kernel: a CPU dataset must fail loudly, not fall back
+
+
+# --------------------------------------------------------------------------- 8(f) items 3 and 4 (host side)
+def test_raw_avi_writer_round_trip(tmp_path):
+    """The container FrameSink writes: RIFF/AVI, 'DIB ' BI_RGB 24-bit, bottom-up rows padded to 4 bytes."""
+    import struct
+    from idealnerf_amd.frame_io import RawAviWriter
+    H, W, N = 6, 5, 3  # W*3 = 15 -> padded rows of 16 bytes
+    rs = np.random.RandomState(0)
+    frames = [rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8) for _ in range(N)]
+    path = str(tmp_path / "v.avi")
+    w = RawAviWriter(path, W, H, fps=25.0)
+    for f in frames:
+        w.write(f)
+    w.release()
+    blob = open(path, "rb").read()
+    assert blob[:4] == b"RIFF" and blob[8:12] == b"AVI " and struct.unpack("<I", blob[4:8])[0] == len(blob) - 8
+    avih = blob.index(b"avih")
+    usec, _, _, flags, total, _, streams, _, width, height = struct.unpack("<10I", blob[avih + 8: avih + 48])
+    assert (usec, total, streams, width, height) == (40000, N, 1, W, H) and flags & 0x10
+    strf = blob.index(b"strf")
+    size, bw, bh, planes, bits, comp = struct.unpack("<IiiHHI", blob[strf + 8: strf + 28])
+    assert (size, bw, bh, planes, bits, comp) == (40, W, H, 1, 24, 0)
+    pos = blob.index(b"movi") + 4
+    for f in frames:
+        assert blob[pos:pos + 4] == b"00db" and struct.unpack("<I", blob[pos + 4:pos + 8])[0] == 16 * H
+        rows = np.frombuffer(blob[pos + 8: pos + 8 + 16 * H], dtype=np.uint8).reshape(H, 16)[:, :15].reshape(H, W, 3)
+        np.testing.assert_array_equal(rows[::-1], f)
+        pos += 8 + 16 * H
+    assert blob[pos:pos + 4] == b"idx1" and struct.unpack("<I", blob[pos + 4:pos + 8])[0] == 16 * N
+    with pytest.raises(ValueError):
+        RawAviWriter(str(tmp_path / "w.avi"), W, H).write(np.zeros((H, W + 1, 3), np.uint8))
+
+
+def test_clip_audio_features_match_reference_loop(golden):
+    """One batched pass over the clip == the reference's frame-by-frame loop (test_torso.py:478-498),
+    including the ends, where the padded slots carry AudioNet(0) rather than zeros."""
+    from idealnerf_amd.models import AudioNet, AudioAttNet, clip_audio_features
+    g = golden("audio_clip")
+    aud_net, att_net = AudioNet(64, 16), AudioAttNet()
+    aud_net.load_state_dict({k[len("audnet."):]: torch.from_numpy(g[k]) for k in g if k.startswith("audnet.")})
+    att_net.load_state_dict({k[len("attnet."):]: torch.from_numpy(g[k]) for k in g if k.startswith("attnet.")})
+    with torch.no_grad():
+        out = clip_audio_features(aud_net, att_net, torch.from_numpy(g["auds"]))
+    assert out.shape == g["out"].shape == (21, 64)
+    assert np.abs(out.numpy() - g["out"]).max() < 2e-6 * max(1.0, np.abs(g["out"]).max())
+    with pytest.raises(ValueError):
+        clip_audio_features(aud_net, att_net, torch.zeros(5, 16, 29))

@@ -885,3 +885,77 @@ def test_dataset_sample_rays_golden(idn, dev, golden):
     assert rel_err(br, g["batch_rays"]) < 1e-6
     np.testing.assert_array_equal(ts.cpu().numpy(), g["target_s"])
     np.testing.assert_array_equal(bs.cpu().numpy(), g["bc_s"])
+
+
+# --------------------------------------------------------------------------- 8(f) items 3 and 4
+def test_to8b_bit_exact_and_nonfinite_flag(idn, dev):
+    """helper.py:154 `(255 * np.clip(x, 0, 1)).astype(np.uint8)` on the device, byte for byte."""
+    rs = np.random.RandomState(5)
+    x = rs.uniform(-0.2, 1.2, size=(257, 33, 3)).astype(np.float32)
+    x.reshape(-1)[:256] = np.arange(256, dtype=np.float32) / np.float32(255.0)   # the exact k/255 grid
+    x.reshape(-1)[256:260] = [0.0, 1.0, -0.0, np.nextafter(np.float32(1.0), np.float32(0.0))]
+    ref = (255 * np.clip(x, 0, 1)).astype(np.uint8)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = idn.ops.to8b(T(x).to(dev), False, flag)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    np.testing.assert_array_equal(idn.ops.to8b(T(x).to(dev), True).cpu().numpy(), ref[..., ::-1])
+    assert int(flag.item()) == 0
+    x[100, 7, 1], x[3, 3, 0] = np.nan, np.inf
+    out = idn.ops.to8b(T(x).to(dev), False, flag).cpu().numpy()
+    assert int(flag.item()) == 1 and out[100, 7, 1] == 0 and out[3, 3, 0] == 255
+    mask = np.isfinite(x)
+    np.testing.assert_array_equal(out[mask], ref[mask])
+
+
+def test_frame_sink_overlapped_copies(idn, dev, tmp_path):
+    """Frames submitted back to back come out in order, byte-identical to the host formula, and the
+    frame holding a NaN is the one reported."""
+    from idealnerf_amd.frame_io import FrameSink
+    H, W, N = 48, 40, 5
+    rs = np.random.RandomState(9)
+    frames = [rs.uniform(-0.1, 1.1, size=(H * W, 3)).astype(np.float32) for _ in range(N)]
+    frames[3][17, 2] = np.nan
+    sink = FrameSink(str(tmp_path / "clip.avi"), W, H, fps=25.0, device=dev, keep_frames=True)
+    for f in frames:
+        sink.submit(T(f).to(dev))
+    sink.release()
+    assert sink.nonfinite_frames == [3] and len(sink.frames) == N
+    for got, f in zip(sink.frames, frames):
+        ref = (255 * np.clip(np.nan_to_num(f, nan=0.0), 0, 1)).astype(np.uint8).reshape(H, W, 3)
+        np.testing.assert_array_equal(got, ref)
+    assert (tmp_path / "clip.avi").stat().st_size > N * H * W * 3
+
+
+def _agg_state(seed):
+    import collections
+    shapes = collections.OrderedDict([("agg_linears.0", (64, 140)), ("agg_linears.1", (64, 64))])
+    c_all = 63 + 64 + 32
+    for i in range(8):
+        shapes[f"pts_linears.{i}"] = (256, c_all if i == 0 else (256 + c_all if i == 5 else 256))
+    shapes.update([("views_linears.0", (128, 27 + 256 + 64)), ("views_linears.1", (128, 128)), ("views_linears.2", (128, 128)),
+                   ("feature_linear", (256, 256)), ("alpha_linear", (1, 256)), ("rgb_linear", (3, 128))])
+    rs = np.random.RandomState(seed)
+    sd = collections.OrderedDict()
+    for k, (o, i) in shapes.items():
+        bound = float(np.sqrt(6.0 / (o + i)))
+        sd[k + ".weight"] = T(rs.uniform(-bound, bound, size=(o, i)).astype(np.float32))
+        sd[k + ".bias"] = torch.full((o,), 0.01, dtype=torch.float32)
+    return sd
+
+
+def test_facenerf_agg_golden(idn, dev, golden):
+    """FaceNeRFAgg (models/face_nerf_agg.py) on the same fused kernel, against the reference module."""
+    g = golden("facenerf_agg")
+    net = idn.FaceNeRFAgg(dim_agg=64, dim_aud=64, dim_expr=76, dim_latent=32)
+    sd = _agg_state(int(g["seed"]))
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    args = [T(g[k]).to(dev) for k in ("x", "aud", "expr", "latent")]
+    with torch.no_grad():
+        out = net(*args)
+        net.precision = "bf16x3"
+        out3 = net(*args)
+    assert rel_err(out, g["out"]) < 1e-5 and rel_err(out3, g["out"]) < 5e-5
+    with pytest.raises(NotImplementedError):
+        net(*args)
