@@ -27,6 +27,8 @@ static int check_precision_f32(int precision) {
 int launch_mlp(int precision, const float* packed, const float* folded, const float* x, const float* rays,
                const float* z, const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw,
                hipStream_t s) {
+    if (n_points > 0x7fffffffLL) return fail(IDN_EUNSUPPORTED, "n_points %lld exceeds 2^31-1 per launch", (long long)n_points);
+    if ((rays || pts) && n_samples < 1) return fail(IDN_EINVAL, "n_samples < 1");
     if (precision == IDN_PREC_BF16X3)
         return launch_mlp_bf16x3(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
     if (precision == IDN_PREC_BF16)

@@ -13,6 +13,8 @@
 // ReLU'd and split into two k-steps of packed hi / lo B operands in registers; element j of
 // k-step s in lane half h is register 8s+j = channel 16s + (j&3) + 8(j>>2) + 4h, which is how
 // pack_bf16x3_kernel orders the weights.
+#include <type_traits>
+
 #include "mlp_common.h"
 
 namespace idn {
@@ -87,9 +89,10 @@ struct SideBf {
 
 // One layer, tile-major: for each n-tile t, KS k-steps of (A_hi, A_lo) x (B_hi, B_lo).
 // On exit `pend` holds the last tile's accumulator (to be converted by the caller / next layer).
-template <int F0, int NT, int KS, bool DEFER, class BHi, class BLo>
+template <int F0, int NT, int KS, bool DEFER, class BHi, class BLo, class Hook = NoHook>
 __device__ __forceinline__ void run_layer_bf(BTile* out, BTile* deferred, f32x16& pend, f32x16 (&acc)[2],
-                                             const float* bias_half, BHi&& bhi, BLo&& blo, WStream& ws, FragReader& fr) {
+                                             const float* bias_half, BHi&& bhi, BLo&& blo, WStream& ws, FragReader& fr,
+                                             Hook&& after_open = NoHook{}) {
     constexpr int NP = NT * KS;
     // the last layer of a pass must not prefetch past itself (see run_layer in mlp_f32.hip)
     constexpr bool LAST = (F0 + 2 * NP == kUsedFrags);
@@ -98,8 +101,11 @@ __device__ __forceinline__ void run_layer_bf(BTile* out, BTile* deferred, f32x16
     const SideBf<NT, KS, DEFER> side{out, deferred, &pend, &acc[0], bias_half};
     if constexpr (F0 % kSliceFrags == 0) {
         ws.open_slice();
+        after_open();
         fr.pref0 = fr.template issue<F0>();
         fr.pref1 = fr.template issue<F0 + 1>();
+    } else {
+        static_assert(std::is_same_v<std::decay_t<Hook>, NoHook>, "a hook needs a layer that starts on a slice boundary");
     }
     f32x4 a0 = fr.pref0, a1 = fr.pref1;
     static_for<NP>([&](auto PI) {
@@ -135,6 +141,26 @@ __device__ __forceinline__ void run_layer_bf(BTile* out, BTile* deferred, f32x16
     fr.pref1 = a1;
 }
 
+// This lane's input features: calls use(fpt, fdir) with two providers, fpt(ic<K0>) / fdir(ic<K0>) =
+// feature K0 + 4h of gamma_10(point) / gamma_4(view direction) (zero beyond 63 / 27).
+template <int MODE, class Use>
+__device__ __forceinline__ void input_features(const MlpArgs& a, long Pc, int h, const PeLane& pln, const PointIn& in,
+                                               Use&& use) {
+    if constexpr (MODE == kModeX) {
+        const float* xr = a.x + Pc * (IDN_PTS_CH + IDN_VIEWS_CH) + 4 * h;
+        use([&](auto K) { constexpr int k = decltype(K)::value; return (k + 4 * h < IDN_PTS_CH) ? xr[k] : 0.0f; },
+            [&](auto K) { constexpr int k = decltype(K)::value; return (k + 4 * h < IDN_VIEWS_CH) ? xr[IDN_PTS_CH + k] : 0.0f; });
+    } else {
+        float p[3], v[3];
+        point_of<MODE>(in, p, v);
+        PeAxes axp, axd;
+        axp.init(p, h);
+        axd.init(v, h);
+        use([&](auto K) { return pe_slot<decltype(K)::value, 10>(axp, pln); },
+            [&](auto K) { return pe_slot<decltype(K)::value, 4>(axd, pln); });
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,6 +179,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
     WStream ws;
     ws.dg = &dg;
     ws.init(a.wstream, kNumSlices, ring, tid, wave);
+    PeLane pln;
+    pln.init(h);
 
     FragReader fr;
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
@@ -160,59 +188,35 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
     const float* bias_h = bias_s + 4 * h;
     const long ntiles = (a.n_points + 127) >> 7;
 
+    PointIn cur, nxt;
+    load_point<MODE>(a, blockIdx.x, wave, m, cur);
+    nxt = cur;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long P = tile * 128 + wave * 32 + m;
         const bool valid = P < a.n_points;
         const long Pc = valid ? P : a.n_points - 1;
 
-        // ---- inputs: 64 point features and 32 direction features of this lane's point
-        float fp[64], fd[32];
-        if constexpr (MODE == kModeX) {
-            const float* xr = a.x + Pc * (IDN_PTS_CH + IDN_VIEWS_CH);
-            static_for<64>([&](auto K) { fp[decltype(K)::value] = decltype(K)::value < IDN_PTS_CH ? xr[decltype(K)::value] : 0.0f; });
-            static_for<32>([&](auto K) { fd[decltype(K)::value] = decltype(K)::value < IDN_VIEWS_CH ? xr[IDN_PTS_CH + decltype(K)::value] : 0.0f; });
-        } else {
-            const long ray = Pc / a.S;
-            float p[3], v[3];
-            if constexpr (MODE == kModeRays) {
-                const float* rr = a.rays + ray * IDN_RAY_FLOATS;
-                const float zz = a.z[Pc];
-                p[0] = rr[0] + rr[3] * zz;  // product and sum rounded separately (-ffp-contract=off)
-                p[1] = rr[1] + rr[4] * zz;
-                p[2] = rr[2] + rr[5] * zz;
-                v[0] = rr[8];
-                v[1] = rr[9];
-                v[2] = rr[10];
-            } else {
-                p[0] = a.pts[Pc * 3 + 0];
-                p[1] = a.pts[Pc * 3 + 1];
-                p[2] = a.pts[Pc * 3 + 2];
-                v[0] = a.dirs[ray * 3 + 0];
-                v[1] = a.dirs[ray * 3 + 1];
-                v[2] = a.dirs[ray * 3 + 2];
-            }
-            encode<10, 64>(p, fp);
-            encode<4, 32>(v, fd);
-        }
-        // k-step fragments of the inputs: element j of k-step s, lane half h = feature 16s + (j&3) + 8(j>>2) + 4h
+        // ---- inputs: this lane's half of the 64 point features and 32 direction features.
+        // Element j of k-step s, lane half h = feature 16s + (j&3) + 8(j>>2) + 4h.
         f32x4 pe_hi[4], pe_lo[4], pd_hi[2], pd_lo[2];
-        auto pack_feats = [&](const float* f, f32x4* ohi, f32x4* olo, auto NKS) {
+        auto pack_feats = [&](auto&& feat, f32x4* ohi, f32x4* olo, auto NKS) {
             static_for<decltype(NKS)::value>([&](auto S_) {
                 constexpr int s = decltype(S_)::value;
                 static_for<4>([&](auto W_) {
                     constexpr int w = decltype(W_)::value;
                     constexpr int j0 = 2 * w, j1 = 2 * w + 1;
                     constexpr int k0 = 16 * s + (j0 & 3) + 8 * (j0 >> 2), k1 = 16 * s + (j1 & 3) + 8 * (j1 >> 2);
-                    const float x0 = h ? f[k0 + 4] : f[k0], x1 = h ? f[k1 + 4] : f[k1];
                     float hw, lw;
-                    split2(x0, x1, hw, lw);
+                    split2(feat(ic<k0>{}), feat(ic<k1>{}), hw, lw);
                     ohi[s][w] = hw;
                     olo[s][w] = lw;
                 });
             });
         };
-        pack_feats(fp, pe_hi, pe_lo, ic<4>{});
-        pack_feats(fd, pd_hi, pd_lo, ic<2>{});
+        input_features<MODE>(a, Pc, h, pln, cur, [&](auto&& fpt, auto&& fdir) {
+            pack_feats(fpt, pe_hi, pe_lo, ic<4>{});
+            pack_feats(fdir, pd_hi, pd_lo, ic<2>{});
+        });
 
         BTile A[8], B[8], V[4];
         f32x16 acc[2], pend;
@@ -234,9 +238,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
             B, &A[7], pend, acc, bias_h + bias_off(5),
             [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 4) return pe_hi[s]; else return A[(s - 4) >> 1].hi[(s - 4) & 1]; },
             [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 4) return pe_lo[s]; else return A[(s - 4) >> 1].lo[(s - 4) & 1]; },
-            ws, fr);
+            ws, fr, [&]() { load_point<MODE>(a, tile + gridDim.x, wave, m, nxt); });
         // ---- pts_linears.6, .7
-        run_layer_bf<layer_f0(6), 8, 16, true>(A, &B[7], pend, acc, bias_h + bias_off(6), tiles_hi(B), tiles_lo(B), ws, fr);
+        run_layer_bf<layer_f0(6), 8, 16, true>(A, &B[7], pend, acc, bias_h + bias_off(6), tiles_hi(B), tiles_lo(B), ws, fr,
+                                               [&]() { touch_point(nxt); });
         run_layer_bf<layer_f0(7), 8, 16, true>(B, &A[7], pend, acc, bias_h + bias_off(7), tiles_hi(A), tiles_lo(A), ws, fr);
         // ---- views_linears.0 (+ alpha_linear as channel 128): [256 | dirPE(32)] -> 160.
         //      Tiles 0..3 are hidden units; tile 4 (last) is never converted: its row 0 is sigma.
@@ -264,6 +269,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
             o.w = sigma;
             *reinterpret_cast<f32x4*>(a.raw + P * 4) = o;
         }
+        cur = nxt;
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -320,9 +326,10 @@ struct SidePlain {
     }
 };
 
-template <int F0, int NT, int KS, bool DEFER, class BGet>
+template <int F0, int NT, int KS, bool DEFER, class BGet, class Hook = NoHook>
 __device__ __forceinline__ void run_layer_plain(PTile* out, PTile* deferred, f32x16& pend, f32x16 (&acc)[2],
-                                                const float* bias_half, BGet&& bget, WStream& ws, FragReader& fr) {
+                                                const float* bias_half, BGet&& bget, WStream& ws, FragReader& fr,
+                                                Hook&& after_open = NoHook{}) {
     constexpr int STEPS = KS / 2, NP = NT * STEPS;
     constexpr bool LAST = (F0 + NT * KS == kPlainUsedFrags);
     static_assert(F0 % 2 == 0 && KS % 2 == 0, "k-steps are consumed in pairs");
@@ -330,8 +337,11 @@ __device__ __forceinline__ void run_layer_plain(PTile* out, PTile* deferred, f32
     const SidePlain<NT, STEPS, DEFER> side{out, deferred, &pend, &acc[0], bias_half};
     if constexpr (F0 % kSliceFrags == 0) {
         ws.open_slice();
+        after_open();
         fr.pref0 = fr.template issue<F0>();
         fr.pref1 = fr.template issue<F0 + 1>();
+    } else {
+        static_assert(std::is_same_v<std::decay_t<Hook>, NoHook>, "a hook needs a layer that starts on a slice boundary");
     }
     f32x4 a0 = fr.pref0, a1 = fr.pref1;
     static_for<NP>([&](auto PI) {
@@ -381,52 +391,37 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs a) {
     WStream ws;
     ws.dg = &dg;
     ws.init(a.wstream, kPlainNumSlices, ring, tid, wave);
+    PeLane pln;
+    pln.init(h);
     FragReader fr;
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
     fr.addr1 = fr.addr0 + 64 * kFragBytes;
     const float* bias_h = bias_s + 4 * h;
     const long ntiles = (a.n_points + 127) >> 7;
 
+    PointIn cur, nxt;
+    load_point<MODE>(a, blockIdx.x, wave, m, cur);
+    nxt = cur;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long P = tile * 128 + wave * 32 + m;
         const bool valid = P < a.n_points;
         const long Pc = valid ? P : a.n_points - 1;
-        float fp[64], fd[32];
-        if constexpr (MODE == kModeX) {
-            const float* xr = a.x + Pc * (IDN_PTS_CH + IDN_VIEWS_CH);
-            static_for<64>([&](auto K) { fp[decltype(K)::value] = decltype(K)::value < IDN_PTS_CH ? xr[decltype(K)::value] : 0.0f; });
-            static_for<32>([&](auto K) { fd[decltype(K)::value] = decltype(K)::value < IDN_VIEWS_CH ? xr[IDN_PTS_CH + decltype(K)::value] : 0.0f; });
-        } else {
-            const long ray = Pc / a.S;
-            float p[3], v[3];
-            if constexpr (MODE == kModeRays) {
-                const float* rr = a.rays + ray * IDN_RAY_FLOATS;
-                const float zz = a.z[Pc];
-                p[0] = rr[0] + rr[3] * zz;
-                p[1] = rr[1] + rr[4] * zz;
-                p[2] = rr[2] + rr[5] * zz;
-                v[0] = rr[8]; v[1] = rr[9]; v[2] = rr[10];
-            } else {
-                p[0] = a.pts[Pc * 3 + 0]; p[1] = a.pts[Pc * 3 + 1]; p[2] = a.pts[Pc * 3 + 2];
-                v[0] = a.dirs[ray * 3 + 0]; v[1] = a.dirs[ray * 3 + 1]; v[2] = a.dirs[ray * 3 + 2];
-            }
-            encode<10, 64>(p, fp);
-            encode<4, 32>(v, fd);
-        }
         f32x4 pe_v[4], pd_v[2];
-        auto pack_feats = [&](const float* f, f32x4* o, auto NKS) {
+        auto pack_feats = [&](auto&& feat, f32x4* o, auto NKS) {
             static_for<decltype(NKS)::value>([&](auto S_) {
                 constexpr int s = decltype(S_)::value;
                 static_for<4>([&](auto W_) {
                     constexpr int w = decltype(W_)::value;
                     constexpr int j0 = 2 * w, j1 = 2 * w + 1;
                     constexpr int k0 = 16 * s + (j0 & 3) + 8 * (j0 >> 2), k1 = 16 * s + (j1 & 3) + 8 * (j1 >> 2);
-                    o[s][w] = __uint_as_float(cvt_pk_bf16(h ? f[k0 + 4] : f[k0], h ? f[k1 + 4] : f[k1]));
+                    o[s][w] = __uint_as_float(cvt_pk_bf16(feat(ic<k0>{}), feat(ic<k1>{})));
                 });
             });
         };
-        pack_feats(fp, pe_v, ic<4>{});
-        pack_feats(fd, pd_v, ic<2>{});
+        input_features<MODE>(a, Pc, h, pln, cur, [&](auto&& fpt, auto&& fdir) {
+            pack_feats(fpt, pe_v, ic<4>{});
+            pack_feats(fdir, pd_v, ic<2>{});
+        });
 
         PTile A[8], B[8], V[4], Vx[5], none[1];
         f32x16 acc[2], pend;
@@ -443,8 +438,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs a) {
             B, &A[7], pend, acc, bias_h + bias_off(5),
             [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 4) return pe_v[s]; else return A[(s - 4) >> 1].v[(s - 4) & 1]; },
             ws, fr);
-        run_layer_plain<plain_f0(6), 8, 16, true>(A, &B[7], pend, acc, bias_h + bias_off(6), tiles(B), ws, fr);
-        run_layer_plain<plain_f0(7), 8, 16, true>(B, &A[7], pend, acc, bias_h + bias_off(7), tiles(A), ws, fr);
+        run_layer_plain<plain_f0(6), 8, 16, true>(A, &B[7], pend, acc, bias_h + bias_off(6), tiles(B), ws, fr,
+                                                  [&]() { load_point<MODE>(a, tile + gridDim.x, wave, m, nxt); });
+        run_layer_plain<plain_f0(7), 8, 16, true>(B, &A[7], pend, acc, bias_h + bias_off(7), tiles(A), ws, fr,
+                                                  [&]() { touch_point(nxt); });
         run_layer_plain<plain_f0(8), 5, 18, true>(
             Vx, &B[7], pend, acc, bias_h + bias_off(8),
             [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 16) return B[s >> 1].v[s & 1]; else return pd_v[s - 16]; },
@@ -464,6 +461,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(MlpArgs a) {
             o.w = sigma;
             *reinterpret_cast<f32x4*>(a.raw + P * 4) = o;
         }
+        cur = nxt;
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();

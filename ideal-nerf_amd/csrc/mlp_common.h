@@ -247,58 +247,100 @@ struct NoSide {
     __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {}
 };
 
-// sin / cos of 2*pi*r for |r| <= 1/8 (Taylor in r; the first dropped terms are < 2e-9).
-__device__ __forceinline__ void sincos_2pi_small(float r, float& sn, float& cs) {
-    const float s = r * r;
-    float ps = 4.2058693945e+01f;                 //  (2pi)^9 / 9!
-    ps = fmaf(ps, s, -7.6705859753e+01f);         // -(2pi)^7 / 7!
-    ps = fmaf(ps, s, 8.1605249276e+01f);          //  (2pi)^5 / 5!
-    ps = fmaf(ps, s, -4.1341702240e+01f);         // -(2pi)^3 / 3!
-    ps = fmaf(ps, s, 6.2831853072e+00f);          //   2pi
-    sn = ps * r;
-    float pc = -2.6426256783e+01f;                // -(2pi)^10 / 10!
-    pc = fmaf(pc, s, 6.0244641371e+01f);          //  (2pi)^8 / 8!
-    pc = fmaf(pc, s, -8.5456817206e+01f);         // -(2pi)^6 / 6!
-    pc = fmaf(pc, s, 6.4939394023e+01f);          //  (2pi)^4 / 4!
-    pc = fmaf(pc, s, -1.9739208802e+01f);         // -(2pi)^2 / 2!
-    cs = fmaf(pc, s, 1.0f);
-}
-
-// gamma_L(v) for a 3-vector, as 3 + 6L features in the reference's order
-// (helper.py:183-201): [v, sin(2^0 v), cos(2^0 v), ..., sin(2^(L-1) v), cos(2^(L-1) v)],
-// zero padded to NF.
+// ---------------------------------------------------------------------------
+// Positional encoding gamma_L(v) of a 3-vector, 3 + 6L features in the reference's order
+// (helper.py:183-201): [v, sin(2^0 v), cos(2^0 v), ..., sin(2^(L-1) v), cos(2^(L-1) v)].
 //
-// The reference evaluates sin/cos of fl32(2^b v), and 2^b v is exact, so the true
-// argument is known exactly: reduce the phase p = v / 2pi once per axis in fp64, double it
-// per band (exact), split off the quadrant (exact) and evaluate a short polynomial on
-// |r| <= 1/8 of a turn.  Measured against torch.sin/cos on CPU: max |diff| 1.2e-7 on every
-// band (<= 2 ulp at 1.0), with no data-dependent branch (ocml's sincosf takes its
-// Payne-Hanek path for the upper bands and cost ~10 % of the kernel).
-template <int L, int NF>
-__device__ __forceinline__ void encode(const float (&v)[3], float (&feat)[NF]) {
-    static_assert(NF >= 3 + 6 * L, "feature buffer too small");
-    static_for<NF>([&](auto K) { feat[decltype(K)::value] = 0.0f; });
-    feat[0] = v[0];
-    feat[1] = v[1];
-    feat[2] = v[2];
-    static_for<3>([&](auto A) {
-        constexpr int a = decltype(A)::value;
-        double p = (double)v[a] * 0.15915494309189535;  // 1 / 2pi
-        static_for<L>([&](auto B) {
-            constexpr int b = decltype(B)::value;
-            p = p - rint(p);                       // [-1/2, 1/2] turns, exact
-            const double q = rint(p * 4.0);        // nearest quarter turn
-            const float r = (float)(p - q * 0.25); // [-1/8, 1/8], exact before the conversion
-            const int qi = (int)q & 3;
-            float sn, cs;
-            sincos_2pi_small(r, sn, cs);
-            const float s_out = (qi & 1) ? cs : sn;
-            const float c_out = (qi & 1) ? sn : cs;
-            feat[3 + 6 * b + a] = (qi == 2 || qi == 3) ? -s_out : s_out;
-            feat[3 + 6 * b + 3 + a] = (qi == 1 || qi == 2) ? -c_out : c_out;
-            p = p + p;
+// The reference evaluates sin/cos of fl32(2^b v), and 2^b v is exact, so the true argument is
+// known exactly (ocml's sincosf takes its Payne-Hanek path for the upper bands and cost ~10 % of
+// the fp32 kernel).  It is evaluated once per feature THE LANE KEEPS: every B-operand slot of the
+// input layers holds feature K0 in the lower lane half and K0 + 4 in the upper one, and both lane
+// halves carry the same point, so computing all features per lane would do the work twice.
+//
+//   feature K >= 3:  t = K - 3, band b = t / 6, sc = (t % 6) / 3 (0 sin, 1 cos), axis a = K % 3
+//                    value = sin(2 pi (frac(2^b x_a / 2pi) + sc / 4))
+//
+// The phase frac(x_a / 2pi) is kept as 64-bit fixed point (from fp64, once per axis); band b is
+// a funnel shift (v_alignbit), cos is a quarter-turn offset, the reduction to the nearest half
+// turn and the sign are integer operations, and ONE odd polynomial on |x| <= pi/2 serves every
+// feature (max |diff| to torch.sin/cos on CPU 1.2e-7 on every band, <= 2 ulp at 1.0).  K0 + 4 has
+// axis (a + 1) % 3, so the upper half stores its axes rotated by one and both halves index axis
+// K0 % 3; band and sc of the two halves enter as per-lane shift / offset operands.
+// ---------------------------------------------------------------------------
+struct PeLane {  // per-lane constants, set once per kernel
+    int h;
+    uint32_t off01, off10;  // (sc << 30) + 2^30 per lane half for (sc_lower, sc_upper) = (0, 1) / (1, 0)
+    __device__ __forceinline__ void init(int h_) {
+        h = h_;
+        off01 = h_ ? 0x80000000u : 0x40000000u;
+        off10 = h_ ? 0x40000000u : 0x80000000u;
+    }
+};
+struct PeAxes {  // one 3-vector of one point, axes rotated by one in the upper lane half
+    uint32_t hi[3], lo[3];
+    float raw[3];
+    __device__ __forceinline__ void init(const float (&v)[3], int h) {
+        uint32_t H[3], Lw[3];
+        static_for<3>([&](auto A) {
+            constexpr int a = decltype(A)::value;
+            const double ph = (double)v[a] * 0.15915494309189535;    // x / 2pi
+            const double t = __builtin_amdgcn_fract(ph) * 4294967296.0;  // turns in [0, 1), scaled exactly
+            H[a] = (uint32_t)t;
+            Lw[a] = (uint32_t)((t - (double)H[a]) * 4294967296.0);
         });
-    });
+        static_for<3>([&](auto A) {
+            constexpr int a = decltype(A)::value, a1 = (a + 1) % 3;
+            hi[a] = h ? H[a1] : H[a];
+            lo[a] = h ? Lw[a1] : Lw[a];
+            raw[a] = h ? v[a1] : v[a];
+        });
+    }
+};
+template <int K, int L>
+struct PeFeat {
+    static constexpr bool raw = K < 3;
+    static constexpr bool trig = K >= 3 && K < 3 + 6 * L;
+    static constexpr int t = trig ? K - 3 : 0;
+    static constexpr int b = t / 6, sc = (t % 6) / 3;
+};
+template <int B>
+__device__ __forceinline__ uint32_t pe_phase(const PeAxes& ax, int a) {
+    if constexpr (B == 0) return ax.hi[a];
+    else return __builtin_amdgcn_alignbit(ax.hi[a], ax.lo[a], 32 - B);  // (hi << B) | (lo >> (32 - B))
+}
+// feature K0 (lower lane half) / K0 + 4 (upper lane half) of gamma_L
+template <int K0, int L>
+__device__ __forceinline__ float pe_slot(const PeAxes& ax, const PeLane& ln) {
+    using F0 = PeFeat<K0, L>;
+    using F1 = PeFeat<K0 + 4, L>;
+    constexpr int a = K0 % 3;
+    if constexpr (!F0::trig && !F1::trig) {
+        if constexpr (F0::raw) return ln.h ? 0.0f : ax.raw[a];
+        else return 0.0f;
+    } else {
+        constexpr int b0 = F0::trig ? F0::b : F1::b, b1 = F1::trig ? F1::b : F0::b;
+        constexpr int sc0 = F0::trig ? F0::sc : F1::sc, sc1 = F1::trig ? F1::sc : F0::sc;
+        uint32_t T;
+        if constexpr (b0 == b1) T = pe_phase<b0>(ax, a);
+        else T = ln.h ? pe_phase<b1>(ax, a) : pe_phase<b0>(ax, a);
+        uint32_t u;
+        if constexpr (sc0 == sc1) u = T + (((uint32_t)sc0 << 30) + 0x40000000u);
+        else u = T + (sc0 == 0 ? ln.off01 : ln.off10);
+        // u = phase + half-turn rounding bias: bit 31 = half-turn parity, the rest - 2^30 = residual
+        const int rr2 = (int)((u << 1) + 0x80000000u);            // residual * 2, signed, |.| <= 2^31
+        const float x = (float)rr2 * 7.3145905512e-10f;           // 2 pi / 2^33 -> |x| <= pi/2
+        const float s2 = x * x;
+        float pp = -2.391218132e-08f;
+        pp = fmaf(pp, s2, 2.752665757e-06f);
+        pp = fmaf(pp, s2, -1.984089153e-04f);
+        pp = fmaf(pp, s2, 8.333331268e-03f);
+        pp = fmaf(pp, s2, -1.666666663e-01f);
+        float r = fmaf(x * s2, pp, x);
+        r = __uint_as_float(__float_as_uint(r) ^ (u & 0x80000000u));
+        if constexpr (!F0::trig) r = ln.h ? r : (F0::raw ? ax.raw[a] : 0.0f);
+        if constexpr (!F1::trig) r = ln.h ? 0.0f : r;
+        return r;
+    }
 }
 
 enum { kModeRays = 0, kModeX = 1, kModePts = 2 };
@@ -316,6 +358,52 @@ struct MlpArgs {
     float* acts;        // training only: activation slab (act_off() matrices of p_pad rows), else null
     long p_pad;
 };
+
+// Raw inputs of one lane's point.  They are loaded one pass ahead (right after a slice opens in
+// the middle of the previous pass and "touched" after the next one, where the slice barrier's
+// vmcnt(0) has already covered them), so a pass starts with its encoding instead of a global-load
+// round trip queued behind the weight pieces issued at the end of the pass before.
+struct PointIn {
+    float f[10];  // kModeRays: o(3) d(3) viewdir(3) z   kModePts: p(3) viewdir(3)   kModeX: unused
+};
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int MODE>
+__device__ __forceinline__ void load_point(const MlpArgs& a, long tile, int wave, int m, PointIn& in) {
+    if constexpr (MODE == kModeX) return;
+    long P = tile * 128 + wave * 32 + m;
+    if (P >= a.n_points) P = a.n_points - 1;  // also covers "no next tile": a valid, unused address
+    const unsigned ray = (unsigned)P / (unsigned)a.S;  // n_points < 2^31 (checked by the launchers)
+    if constexpr (MODE == kModeRays) {
+        const float* rr = a.rays + (long)ray * IDN_RAY_FLOATS;
+        in.f[0] = rr[0]; in.f[1] = rr[1]; in.f[2] = rr[2];
+        in.f[3] = rr[3]; in.f[4] = rr[4]; in.f[5] = rr[5];
+        in.f[6] = rr[8]; in.f[7] = rr[9]; in.f[8] = rr[10];
+        in.f[9] = a.z[P];
+    } else {
+        in.f[0] = a.pts[P * 3 + 0]; in.f[1] = a.pts[P * 3 + 1]; in.f[2] = a.pts[P * 3 + 2];
+        in.f[3] = a.dirs[(long)ray * 3 + 0]; in.f[4] = a.dirs[(long)ray * 3 + 1]; in.f[5] = a.dirs[(long)ray * 3 + 2];
+    }
+}
+__device__ __forceinline__ void touch_point(PointIn& in) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) asm volatile("" : "+v"(in.f[i]));
+}
+// point and view direction of the lane (pts = rays_o + rays_d * z with product and sum rounded
+// separately, audio_exp_nerf.py:332; this code is built with -ffp-contract=off)
+template <int MODE>
+__device__ __forceinline__ void point_of(const PointIn& in, float (&p)[3], float (&v)[3]) {
+    if constexpr (MODE == kModeRays) {
+        p[0] = in.f[0] + in.f[3] * in.f[9];
+        p[1] = in.f[1] + in.f[4] * in.f[9];
+        p[2] = in.f[2] + in.f[5] * in.f[9];
+        v[0] = in.f[6]; v[1] = in.f[7]; v[2] = in.f[8];
+    } else {
+        p[0] = in.f[0]; p[1] = in.f[1]; p[2] = in.f[2];
+        v[0] = in.f[3]; v[1] = in.f[4]; v[2] = in.f[5];
+    }
+}
 
 constexpr int kMlpLds = kRingFrags * kFragBytes + kBiasFloats * 4;
 constexpr int kStagePitch = 33;                       // 32x32 transpose tile, conflict-free

@@ -149,6 +149,8 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
     WStream ws;
     ws.dg = &dg;
     ws.init(a.wstream, kNumSlices, ring, tid, wave);
+    PeLane pln;
+    pln.init(h);
 
     FragReader fr;
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
@@ -202,19 +204,14 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
                 v[1] = a.dirs[ray * 3 + 1];
                 v[2] = a.dirs[ray * 3 + 2];
             }
-            float fp[64], fd[32];
-            encode<10, 64>(p, fp);
-            encode<4, 32>(v, fd);
+            PeAxes axp, axd;
+            axp.init(p, h);
+            axd.init(v, h);
             static_for<8>([&](auto G) {
                 static_for<4>([&](auto J) {
                     constexpr int g = decltype(G)::value, j = decltype(J)::value;
-                    pe[g][j] = h ? fp[8 * g + 4 + j] : fp[8 * g + j];
-                });
-            });
-            static_for<4>([&](auto G) {
-                static_for<4>([&](auto J) {
-                    constexpr int g = decltype(G)::value, j = decltype(J)::value;
-                    pd[g][j] = h ? fd[8 * g + 4 + j] : fd[8 * g + j];
+                    pe[g][j] = pe_slot<8 * g + j, 10>(axp, pln);
+                    if constexpr (g < 4) pd[g][j] = pe_slot<8 * g + j, 4>(axd, pln);
                 });
             });
         }
