@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-mode", action="store_true", help="skip the exact-fp32 side measurement (profiling runs)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default=os.environ.get("IDN_PRECISION", "bf16x3"),
                     help="arithmetic of the MLP contraction; f32 and bf16x3 meet the 1e-4 RGB parity bar "
@@ -201,10 +202,10 @@ def main():
     if rank == 0:
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the
         # process, so the figure comes from the committed rocprofv3 --pmc passes of this same command
-        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r01_pmc_mlp_f32.json).
+        # (tools/profile_round.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes).
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mlp_f32.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_mlp_{args.precision}_final.json")))
             if H == 512 and world == 1:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
@@ -217,8 +218,6 @@ def main():
         kname = {"f32": "idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)",
                  "bf16x3": "idn::mlp_bf16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 bf16 MFMAs per product)",
                  "bf16": "idn::mlp_bf16_kernel<kModeRays> (fused PE + FaceNeRF MLP, plain bf16 MFMA)"}[args.precision]
-        if args.precision != "f32":
-            traffic = None
         res = {
             "metric": "ray-samples/sec (64+128 pts, 512x512), whole job", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -235,7 +234,7 @@ def main():
                          "flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": (k_pts.value / k_n.value) if k_n.value else None,
                          "kernel_time_share": (k_ms.value * 1e-3) / dt if dt > 0 else None},
         }
-        if world == 1 and args.precision != "f32":
+        if world == 1 and args.precision != "f32" and not args.no_f32_mode:
             # the exact-fp32 mode of the same kernel family, measured after the timed region (2 frames)
             coarse.precision = fine.precision = "f32"
             p32c, p32f = coarse.packed_weights(), fine.packed_weights()
