@@ -34,6 +34,7 @@ struct NNArgs {
     float* C; int ldc;
     const float* mask; int ldm;
     int K;
+    int m_tiles, n_blocks;
 };
 constexpr int kNNPitchA = 36;  // 128 x 32 A tile, ds_read_b128 conflict-free (pitch = 4 mod 32 dwords)
 
@@ -42,8 +43,14 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs g) {
     __shared__ __attribute__((aligned(16))) float Bs[32 * 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
-    const long m0 = (long)blockIdx.x * 128;
-    const int n0 = blockIdx.y * 64;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8, so the n_blocks column blocks that read
+    // the same 128 rows of A are given consecutive slots of ONE XCD and share them through its L2
+    // (with the row-major order A came from HBM once per column block: 4x the algorithmic bytes).
+    const int slot = blockIdx.x >> 3;
+    const int mt = (slot / g.n_blocks) * 8 + (blockIdx.x & 7);
+    if (mt >= g.m_tiles) return;
+    const long m0 = (long)mt * 128;
+    const int n0 = (slot % g.n_blocks) * 64;
     f32x16 acc[2];
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 
@@ -176,16 +183,43 @@ __global__ void reduce_partials_kernel(const float* part, int splits, int N, int
     out[(long)n * ldo + k] = (float)s;
 }
 
-// part[blk][c] = sum over the block's rows of A[p][c]
-__global__ void colsum_kernel(const float* A, int lda, long P, int C, long rows_per_block, float* part) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
+// part[blk][c] = sum over the block's rows of A[p][c]   (bias gradients: HBM-bound, one pass over A)
+// A block owns rows_per_block consecutive rows; its 256 threads are CQ column quads x 256/CQ row
+// lanes, each summing every (256/CQ)-th row of its four columns in fp64 (16-byte loads, eight in
+// flight); the row lanes are then added in a fixed order, so the result is deterministic.
+template <int CQ>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, long P, int C,
+                                                     long rows_per_block, float* __restrict__ part) {
+    constexpr int RL = 256 / CQ;
+    __shared__ double red[RL][CQ * 4];
+    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
     const long p0 = (long)blockIdx.x * rows_per_block;
     long p1 = p0 + rows_per_block;
     if (p1 > P) p1 = P;
-    double s = 0.0;
-    for (long p = p0; p < p1; ++p) s += (double)A[p * lda + c];
-    part[(long)blockIdx.x * C + c] = (float)s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int c0 = 4 * cq;
+    if (c0 + 3 < C && (lda & 3) == 0) {
+#pragma unroll 8
+        for (long p = p0 + rl; p < p1; p += RL) {
+            const float4 v = *reinterpret_cast<const float4*>(A + p * lda + c0);
+            s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+        }
+    } else if (c0 < C) {
+        for (long p = p0 + rl; p < p1; p += RL) {
+            const float* r = A + p * lda + c0;
+            s0 += (double)r[0];
+            if (c0 + 1 < C) s1 += (double)r[1];
+            if (c0 + 2 < C) s2 += (double)r[2];
+            if (c0 + 3 < C) s3 += (double)r[3];
+        }
+    }
+    red[rl][c0 + 0] = s0; red[rl][c0 + 1] = s1; red[rl][c0 + 2] = s2; red[rl][c0 + 3] = s3;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double t = 0.0;
+        for (int r = 0; r < RL; ++r) t += red[r][c];
+        part[(long)blockIdx.x * C + c] = (float)t;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -407,8 +441,9 @@ size_t bwd_workspace_bytes(int64_t n_points) {
 
 static int run_nn(const float* A, int lda, const float* B, int ldb, int b_rows, const float* extra, int extra_at,
                   float* C, int ldc, const float* mask, int ldm, int64_t M, int N, int K, hipStream_t s) {
-    NNArgs g{A, lda, B, ldb, b_rows, extra, extra_at, C, ldc, mask, ldm, K};
-    hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)(M / 128), N / 64), dim3(256), 0, s, g);
+    const int m_tiles = (int)(M / 128), n_blocks = N / 64;
+    NNArgs g{A, lda, B, ldb, b_rows, extra, extra_at, C, ldc, mask, ldm, K, m_tiles, n_blocks};
+    hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)((m_tiles + 7) / 8 * 8 * n_blocks)), dim3(256), 0, s, g);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }
@@ -458,7 +493,9 @@ static int run_tn(const float* A, int lda, int N, const float* B, int ldb, int K
 static int run_colsum(const float* A, int lda, int64_t P, int C, float* cpart, float* out, hipStream_t s) {
     const long rpb = (P + kColsumBlocks - 1) / kColsumBlocks;
     const int blocks = (int)((P + rpb - 1) / rpb);
-    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
+    if (C <= 4) hipLaunchKernelGGL(colsum_kernel<1>, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
+    else if (C <= 128) hipLaunchKernelGGL(colsum_kernel<32>, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
+    else hipLaunchKernelGGL(colsum_kernel<64>, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
     IDN_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, cpart, blocks, 1, C, out, C, 1, C);
     IDN_HIP_CHECK(hipGetLastError());
