@@ -173,14 +173,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 }
 
 // out[n*ldo + k] = sum_s part[s][n][k],  n < rows, k < cols  (rows/cols may be smaller than N/K: padding dropped)
-__global__ void reduce_partials_kernel(const float* part, int splits, int N, int K, float* out, int ldo, int rows,
-                                       int cols) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * cols) return;
-    const int n = idx / cols, k = idx % cols;
+// 64 outputs x 4 split lanes per block: lane q adds splits q, q+4, ... in fp64, the four lanes are
+// then added in a fixed order (deterministic), so 4x as many loads are in flight per output.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, int N, int K,
+                                                              float* __restrict__ out, int ldo, int rows, int cols) {
+    __shared__ double red[4][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
+    const bool live = idx < rows * cols;
+    const int n = live ? idx / cols : 0, k = live ? idx % cols : 0;
     double s = 0.0;
-    for (int sp = 0; sp < splits; ++sp) s += (double)part[((long)sp * N + n) * K + k];
-    out[(long)n * ldo + k] = (float)s;
+    if (live) {
+        const float* src = part + (long)n * K + k;
+        const long stride = (long)N * K;
+#pragma unroll 8
+        for (int sp = q; sp < splits; sp += 4) s += (double)src[sp * stride];
+    }
+    red[q][o] = s;
+    __syncthreads();
+    if (q == 0 && live) out[(long)n * ldo + k] = (float)(((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
 }
 
 // part[blk][c] = sum over the block's rows of A[p][c]   (bias gradients: HBM-bound, one pass over A)
@@ -478,7 +489,7 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
 static int run_reduce(const float* part, int splits, int N, int K, int row0, float* out, int ldo, int rows, int cols,
                       hipStream_t s) {
     const int total = rows * cols;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part + (size_t)row0 * K,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part + (size_t)row0 * K,
                        splits, N, K, out, ldo, rows, cols);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
@@ -497,7 +508,7 @@ static int run_colsum(const float* A, int lda, int64_t P, int C, float* cpart, f
     else if (C <= 128) hipLaunchKernelGGL(colsum_kernel<32>, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
     else hipLaunchKernelGGL(colsum_kernel<64>, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
     IDN_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, cpart, blocks, 1, C, out, C, 1, C);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, s, cpart, blocks, 1, C, out, C, 1, C);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }
