@@ -35,16 +35,15 @@ def _stale(target, deps):
 
 
 def build_diag(verbose=True, define="-DIDN_DIAG", tag="diag"):
-    """Diagnostic variants: libidealnerf_diag.so (cycle stamps in the MLP kernel) or, with
-    define=-DIDN_DIAG_NOSTREAM, libidealnerf_nostream.so (timing-only: the weight prefetch is
-    dropped after the prologue, outputs are garbage).  Never loaded by the package unless IDN_LIB
-    points at them."""
+    """Variant builds for diagnostics and same-box A/Bs: libidealnerf_<tag>.so compiled with an
+    extra -D define (default: cycle stamps in the fp32 MLP kernel).  Never loaded by the package
+    unless IDN_LIB points at them (tools/ab_bench.sh)."""
     obj = os.path.join(OBJ, tag)
     os.makedirs(obj, exist_ok=True)
     objs = []
     for src in SOURCES:
         o = os.path.join(obj, src.replace(".hip", ".o"))
-        cmd = [hipcc()] + FLAGS + [define, "-c", os.path.join(CSRC, src), "-o", o]
+        cmd = [hipcc()] + FLAGS + define.split() + ["-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -86,7 +85,5 @@ def build(force=False, verbose=True):
 if __name__ == "__main__":
     if "--diag" in sys.argv:
         print(build_diag())
-    elif "--nostream" in sys.argv:
-        print(build_diag(define="-DIDN_DIAG_NOSTREAM", tag="nostream"))
     else:
         print(build(force="--force" in sys.argv))

@@ -54,39 +54,36 @@ struct Diag {};
 // ---------------------------------------------------------------------------
 // weight stream: global -> LDS ring
 //
-// The ring holds kRingSlots slices (idn_internal.h).  A slice is fetched by "pieces" (one
-// global_load_lds_dwordx4 per wave each = 4 KiB per piece); while slice s is consumed, the
-// pieces of slice s + kRingSlots-1 are issued, one per fragment-pair step, into the slot slice
-// s-1 just vacated.  A slice is opened by a COUNTED wait + raw barrier: s_waitcnt vmcnt(N)
-// leaves the N pieces of the younger slices in flight (N = 0 for the two-slot ring).  Other
-// vector-memory operations of the wave only make the counted wait stricter.
+// The ring holds kRingSlots slices (idn_internal.h).  A slice is fetched by "pieces": one
+// buffer_load_dwordx4 ... lds per wave each, i.e. NW KiB per piece for a workgroup of NW waves.
+// While slice s is consumed, the pieces of slice s + kRingSlots-1 are issued, one per
+// fragment-pair step, into the slot slice s-1 just vacated.  A slice is opened by a COUNTED wait +
+// raw barrier: s_waitcnt vmcnt(N) leaves the N pieces of the younger slices in flight (N = 0 for
+// the two-slot ring).  Other vector-memory operations of the wave only make the wait stricter.
+//
+// Piece form: descriptor (4 SGPRs) + one constant VGPR (lane * 16) + a scalar stream offset.
+// Beside an MFMA chain (tools/glds_ubench.hip) it costs the issuing wave about half of
+// global_load_lds with per-lane 64-bit pointers and the clock holds higher.  The descriptor's
+// num_records bounds every piece to the stream (out of range reads zeros instead of faulting).
+// What was tried and made no difference: issuing 2 or 4 pieces per step, staggering the
+// workgroups of an XCD, never waiting for the pieces (timing-only) -- DESIGN.md section 3.
 // ---------------------------------------------------------------------------
-constexpr int kPieces = kSliceFrags / 4;                    // pieces per slice
-#ifndef IDN_PIECES_PER_STEP
-#define IDN_PIECES_PER_STEP 1
-#endif
-constexpr int kPiecesPerStep = IDN_PIECES_PER_STEP;         // pieces issued per fragment-pair step
-static_assert(kPieces % kPiecesPerStep == 0, "a slice is a whole number of steps");
-constexpr int kAhead = kRingSlots - 1;                      // slices in flight ahead of the consumer
-constexpr int kVmcntOpen = (kAhead - 1) * kPieces;          // younger pieces allowed in flight at a barrier
-static_assert(kVmcntOpen == 0 || kVmcntOpen == 8 || kVmcntOpen == 16, "add the s_waitcnt literal below");
+constexpr int kAhead = kRingSlots - 1;  // slices in flight ahead of the consumer
 
-struct WStream {
+template <int NW>
+struct WStreamT {
+    static constexpr int kPieceBytes = NW * kFragBytes;
+    static constexpr int kPieces = kSliceBytes / kPieceBytes;     // pieces per slice
+    static constexpr int kVmcntOpen = (kAhead - 1) * kPieces;      // younger pieces allowed in flight at a barrier
+    static_assert(kVmcntOpen == 0 || kVmcntOpen == 8 || kVmcntOpen == 16, "add the s_waitcnt literal below");
+
     Diag* dg;
-    // Pieces are buffer_load_dwordx4 ... lds: descriptor (4 SGPRs) + one constant VGPR (lane * 16) +
-    // a scalar stream offset.  Measured beside an MFMA chain (tools/glds_ubench.hip) a piece in
-    // this form costs the issuing wave ~1.5 cycles against ~8 for global_load_lds with per-lane
-    // 64-bit pointers, and the clock holds ~10 % higher.  The descriptor's num_records bounds
-    // every piece to the stream (an out-of-range piece reads zeros instead of faulting).
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff;      // this lane's 16-byte column inside a piece
     uint32_t soff;      // byte offset of the slice currently being fetched (wave-uniform)
     int next_slice;
     int num_slices;     // slices in this stream (kNumSlices, or kPlainNumSlices for the plain-bf16 stream)
     char* ring_wave;    // ring + wave * 1 KiB (wave-uniform LDS destination base)
-#ifdef IDN_DIAG_NOSTREAM
-    bool pass_done = true;  // set false to drop all prefetch pieces after the prologue
-#endif
 
     __device__ __forceinline__ void init(const float* stream, int slices, char* ring, int tid, int wave) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, slices * kSliceBytes, 0x00020000);  // raw, untyped
@@ -95,7 +92,7 @@ struct WStream {
         next_slice = 0;
         num_slices = slices;
         ring_wave = ring + wave * kFragBytes;
-        prologue();
+        static_for<kAhead>([&](auto S_) { issue_rest<decltype(S_)::value, 0>(); });  // slices 0 .. kAhead-1
     }
     __device__ __forceinline__ void advance() {
         soff += kSliceBytes;
@@ -106,37 +103,19 @@ struct WStream {
     }
     template <int SLOT, int J>
     __device__ __forceinline__ void issue_piece() {
-#ifdef IDN_DIAG_NOSTREAM  // timing-only experiment: what does the weight stream cost? (outputs are garbage)
-        if (pass_done)
-#endif
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(ring_wave + SLOT * kSliceBytes + J * 4096), 16, voff,
-                                                 soff + J * 4096, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(ring_wave + SLOT * kSliceBytes + J * kPieceBytes), 16, voff,
+                                                 soff + J * kPieceBytes, 0, 0);
         if constexpr (J == kPieces - 1) advance();
     }
     template <int SLOT, int J0>
     __device__ __forceinline__ void issue_rest() {
         static_for<kPieces - J0>([&](auto I) { issue_piece<SLOT, J0 + decltype(I)::value>(); });
     }
-    // kernel start: slices 0 .. kAhead-1 into slots 0 .. kAhead-1
-    __device__ __forceinline__ void prologue() {
-#ifdef IDN_STAGGER  // experiment: spread the workgroups of an XCD over one slice period
-        for (int i = (blockIdx.x >> 3) & 31; i > 0; --i) __builtin_amdgcn_s_sleep(IDN_STAGGER);
-#endif
-        static_for<kAhead>([&](auto S_) { issue_rest<decltype(S_)::value, 0>(); });
-#ifdef IDN_DIAG_NOSTREAM
-        pass_done = false;
-#endif
-    }
-    // Open the next slice: this wave's pieces of it have landed (all but the 16 youngest
-    // vector-memory operations are complete); after the barrier every wave's have, and every
-    // wave is done reading the slot the next pieces will overwrite.
+    // Open the next slice: this wave's pieces of it have landed; after the barrier every wave's
+    // have, and every wave is done reading the slot the next pieces will overwrite.
     __device__ __forceinline__ void open_slice() {
         DIAG_BEGIN(*dg);
-#ifdef IDN_DIAG_NOWAIT  // timing-only experiment: pieces are issued but never waited for (outputs are garbage)
-        if constexpr (false) {}
-#else
         if constexpr (kVmcntOpen == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         else if constexpr (kVmcntOpen == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -148,10 +127,10 @@ struct WStream {
     __device__ __forceinline__ void step_piece() {
         constexpr int jpos = (F % kSliceFrags) / 2;
         constexpr int slot = (F / kSliceFrags + kAhead) % kRingSlots;
-        if constexpr (jpos * kPiecesPerStep < kPieces)
-            static_for<kPiecesPerStep>([&](auto I) { issue_piece<slot, jpos * kPiecesPerStep + decltype(I)::value>(); });
+        if constexpr (jpos < kPieces) issue_piece<slot, jpos>();
     }
 };
+using WStream = WStreamT<4>;
 
 // ---------------------------------------------------------------------------
 // A-fragment reads.  hipcc (ROCm 7.2) waits lgkmcnt(0) after a prefetching ds_read -- i.e.
@@ -187,8 +166,8 @@ struct FragReader {
 // End of a pass: walk the unused tail of the stream (padding) without reading it, so that the
 // barriers and prefetch pieces scheduled on those positions still happen and the next pass
 // finds its first kAhead slices in flight.
-template <int F_END, int STREAM_FRAGS = kStreamFrags>
-__device__ __forceinline__ void finish_pass(WStream& ws) {
+template <int F_END, int STREAM_FRAGS = kStreamFrags, class WS>
+__device__ __forceinline__ void finish_pass(WS& ws) {
     static_assert(F_END % 2 == 0, "pairs");
     static_for<(STREAM_FRAGS - F_END) / 2>([&](auto I) {
         constexpr int f = F_END + 2 * decltype(I)::value;
@@ -217,17 +196,14 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[NT], const float* bias_h
     static_for<NT>([&](auto T) { bias_tile(acc[decltype(T)::value], bias_half + 32 * decltype(T)::value); });
 }
 
-// ReLU as exactly one VALU instruction.  Written as asm because every builtin spelling (fmaxf,
-// fmed3) is canonicalised by hipcc into v_max_f32 x,x ; v_max_f32 0,x -- twice the issue slots,
-// in the part of the kernel where VALU issue is what the MFMA chain competes with.
+// ReLU as exactly one VALU instruction the compiler can see: a signed-integer max of the bit
+// pattern with 0 (negative floats, -0.0 included, are negative integers).  The float spellings
+// (fmaxf, fmed3) are canonicalised by hipcc into v_max_f32 x,x ; v_max_f32 0,x -- twice the issue
+// slots -- and an inline-asm v_max_f32 is invisible to the hazard recogniser: where the accumulators
+// live in VGPRs (the 8-wave plain-bf16 kernel) it read MFMA results before they were written.
 __device__ __forceinline__ float relu1(float x) {
-#ifdef IDN_RELU_BUILTIN  // A/B arm
-    return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
-#else
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
-#endif
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 // ReLU, in place, of registers [R0, R0 + CNT) of a tile (clipped to the 16 a tile has)
 template <int R0, int CNT>
@@ -369,10 +345,10 @@ struct PointIn {
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
-template <int MODE>
+template <int MODE, int NW = 4>
 __device__ __forceinline__ void load_point(const MlpArgs& a, long tile, int wave, int m, PointIn& in) {
     if constexpr (MODE == kModeX) return;
-    long P = tile * 128 + wave * 32 + m;
+    long P = tile * (32 * NW) + wave * 32 + m;
     if (P >= a.n_points) P = a.n_points - 1;  // also covers "no next tile": a valid, unused address
     const unsigned ray = (unsigned)P / (unsigned)a.S;  // n_points < 2^31 (checked by the launchers)
     if constexpr (MODE == kModeRays) {
