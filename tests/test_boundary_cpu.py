@@ -225,6 +225,14 @@ def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
         assert "0 suspicious touches" in r.stdout
+    # the auditor's second check (inline-asm VALU reading a VGPR an MFMA has just written: the
+    # plain-bf16 kernel keeps its accumulators in VGPRs) must fire on a known-bad sequence
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Z11fake_kernelv:\n\tv_mfma_f32_32x32x16_bf16 v[0:15], v[20:23], v[24:27], v[0:15]\n"
+                   "\t;;#ASMSTART\n\tv_max_f32 v3, 0, v3\n\t;;#ASMEND\n\ts_endpgm\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(bad)],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "written by an MFMA" in r.stdout
 
 
 def test_config_files_parse_like_the_reference(idn):

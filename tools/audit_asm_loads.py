@@ -7,7 +7,15 @@ instruction that reads or writes those registers before the asm `s_waitcnt lgkmc
 retires them sees/destroys garbage (cdna_hip_programming.md 5.7).  This script walks each
 kernel in a .s file in program order (straight-line approximation), tracks the destination
 ranges of asm ds_reads and reports every non-asm instruction that touches a range while it is
-in flight.  Usage: audit_asm_loads.py file.s [kernel-name-substring]
+in flight.
+
+Second check, same walk: an inline-asm VALU instruction that reads a VGPR an MFMA wrote a few
+instructions earlier.  The hazard recogniser inserts the wait states an MFMA result needs before
+a VALU read only for instructions it can see; with accumulators in AGPRs a visible
+v_accvgpr_read always sits in between, with VGPR accumulators (two waves per SIMD, <= 256
+registers) an asm ReLU read the result early and returned garbage.
+
+Usage: audit_asm_loads.py file.s [kernel-name-substring]
 """
 import re, sys
 
@@ -21,8 +29,10 @@ def regs(tok):
 
 def audit(lines, name):
     inflight = []   # list of (regset, line_no) in issue order
+    mfma_dst = []   # (regset of VGPR destinations, instruction index) of recent MFMAs
     in_asm = False
     bad = 0
+    idx = 0
     for no, ln in lines:
         s = ln.strip()
         if s.startswith(';;#ASMSTART') or '#ASMSTART' in s:
@@ -32,6 +42,23 @@ def audit(lines, name):
         if not s or s.startswith(';') or s.startswith('.') or s.endswith(':'):
             continue
         code = s.split(';')[0]
+        idx += 1
+        mfma_dst = [(r, i) for r, i in mfma_dst if idx - i <= 20]   # 16-pass MFMA -> VALU read: 18 wait states
+        if in_asm and code.startswith('v_') and not code.startswith('v_mfma'):
+            srcs = regs(' '.join(code.split()[2:]))
+            for d, i in mfma_dst:
+                hit = srcs & d
+                if hit:
+                    bad += 1
+                    if bad <= 12:
+                        print(f"  {name}: line {no}: asm `{code.strip()}` reads {sorted(hit)[:4]} written by an MFMA {idx - i} instructions earlier")
+        if code.startswith('v_mfma'):
+            d = {x for x in regs(code.split()[1].rstrip(',')) if x[0] == 'v'}
+            if d:
+                mfma_dst.append((d, idx))
+        elif code.startswith(('v_', 'ds_read', 'global_load', 'buffer_load', 'scratch_load')) and len(code.split()) > 1:
+            over = regs(code.split()[1].rstrip(','))          # a later writer owns the register again
+            mfma_dst = [(r - over, i) for r, i in mfma_dst]
         if in_asm:
             if code.startswith('ds_read_b128'):
                 dst = code.split()[1].rstrip(',')
