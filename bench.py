@@ -90,9 +90,9 @@ def bench_train(args):
     mouth = rs.choice((yy * W + xx).reshape(-1), 512, replace=False)
     border = rs.choice(np.arange(0, 60 * W), 128, replace=False)
     sel = torch.from_numpy(np.concatenate([uni, mouth, border]))
-    import oracle  # only for the pinhole ray table of the synthetic pose (host-side input generation)
-    ro, rd = oracle.camera_rays(H, W, syn["focal"], syn["c2w"])
-    batch_rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0).to(dev)
+    from idealnerf_amd import ops
+    rec = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], device=dev)  # [H*W, 11]: o, d, ...
+    batch_rays = torch.stack([rec[sel.to(dev), 0:3], rec[sel.to(dev), 3:6]], 0).contiguous()
     bg = syn["bc"].reshape(-1, 3)[sel].contiguous().to(dev)
     tgt = torch.from_numpy(rs.uniform(0, 1, size=(len(sel), 3)).astype(np.float32)).to(dev)
     auds = torch.from_numpy(rs.standard_normal((8, 16, 29)).astype(np.float32)).to(dev)
@@ -117,6 +117,74 @@ def bench_train(args):
                       "algorithmic_tflops": samples * 3 * FLOP_PER_SAMPLE / dt / 1e12, "final_loss": float(info["loss"])}))
 
 
+def bench_torso(args):
+    """BASELINE configs[4]: HeadNeRF + TorsoNeRF two-stage composite, plain-bf16 MFMA MLP, frame-parallel
+    (rank r renders its own frames, no collective on the data path: weak scaling).  A step = one
+    composited 512x512 frame = two full renders (head C=235, torso C=169).  Secondary measurement."""
+    import idealnerf_amd
+    from idealnerf_amd import synthetic
+    from idealnerf_amd.helper import RenderConfig
+    from idealnerf_amd.train_torso import Network
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    H = W = args.size
+    prec = args.precision if args.precision_given else "bf16"
+    syn = synthetic.frame(H, W, seed=rank)   # every rank renders a different frame of the clip
+    cfg = RenderConfig(perturb=0.0, chunk=32768, near=syn["near"], far=syn["far"], dim_expr=76)
+    net = Network(H, W, syn["focal"], syn["near"], syn["far"], 32768, None, 64, 128, args=cfg, dim_expr_head=76).to(dev).eval()
+    for i, m in enumerate((net.face_nerf_coarse, net.face_nerf_fine, net.torso_coarse_nerf, net.torso_fine_nerf)):
+        synthetic.xavier_state_dict(m, 2 + i, 300.0 if i < 2 else 4.0, 0.3 if i < 2 else -0.2)
+        m.precision = prec
+    g = lambda t: t.to(dev)
+    aud, expr, latent, bc = g(syn["aud"]), g(syn["expr"]), g(syn["latent"]), g(syn["bc"])
+    pose = g(torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0))
+    kw = dict(H=H, W=W, focal=syn["focal"], render_poses=pose[:3, :4], chunk=32768, near=syn["near"], far=syn["far"], bc_rgb=bc)
+
+    def step():
+        aud_torso = net.torso_signal(aud, pose)
+        rgb, _, _, _, _, _ = net.render_pair(expr=expr, latent_code=latent, aud_para=aud,
+                                             network_nerf={"coarse": net.face_nerf_coarse, "fine": net.face_nerf_fine}, **kw)
+        _, _, _, lw_t, fg_t, _ = net.render_pair(expr=None, latent_code=None, aud_para=aud_torso,
+                                                 network_nerf={"coarse": net.torso_coarse_nerf, "fine": net.torso_fine_nerf}, **kw)
+        return rgb * lw_t[..., None] + fg_t   # train_torso.py:269
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frame = step()
+        fence()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        samples = world * args.steps * H * W * 2 * 256
+        print(json.dumps({"metric": "ray-samples/sec (head + torso composite, 64+128 pts each, whole job)", "value": samples / dt,
+                          "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": prec, "data": "synthetic",
+                          "frames_per_s": world * args.steps / dt,
+                          "config": {"workload": f"BASELINE configs[4]: HeadNeRF+TorsoNeRF composite, {H}x{W}, frame-parallel",
+                                     "nets": "head C=235 (aud 64, expr 76, latent 32) + torso C=169 (aud 64 + pose PE 42)"},
+                          "finite": bool(torch.isfinite(frame).all())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,11 +197,15 @@ def main():
                     help="arithmetic of the MLP contraction; f32 and bf16x3 meet the 1e-4 RGB parity bar "
                          "(tests/test_hip_parity.py), bf16x3 is 3.4x faster and the default; bf16 (plain, ~1e-2) "
                          "only meets BASELINE config 5's PSNR criterion and is never the headline number")
-    ap.add_argument("--workload", choices=["frame", "train"], default="frame",
-                    help="frame = BASELINE configs[1] (default, the headline metric); train = configs[2] train step")
+    ap.add_argument("--workload", choices=["frame", "train", "torso"], default="frame",
+                    help="frame = BASELINE configs[1] (default, the headline metric); train = configs[2] train step; "
+                         "torso = configs[4] head+torso composite frames, plain bf16, frame-parallel")
     args = ap.parse_args()
+    args.precision_given = any(a.startswith("--precision") for a in sys.argv[1:]) or "IDN_PRECISION" in os.environ
     if args.workload == "train":
         return bench_train(args)
+    if args.workload == "torso":
+        return bench_torso(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
