@@ -2,6 +2,7 @@
 // gfx950 only.  See DESIGN.md for the data layout this header encodes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/idealnerf.h"
@@ -112,6 +113,33 @@ int fail(int code, const char* fmt, ...);
         hipError_t _e = (expr);                                                               \
         if (_e != hipSuccess) return ::idn::fail(IDN_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
+
+// ---------------------------------------------------------------------------
+// Per-device launch state of a kernel family: the CU count (grid = min(tiles, CUs)) and the
+// dynamic-LDS opt-in, done once per device under a lock.  The reference may run its model under
+// nn.DataParallel (one host thread per device in ONE process): launches are
+// re-entrant per device and stream.
+// ---------------------------------------------------------------------------
+struct LaunchSetup {
+    static constexpr int kMaxDevices = 64;
+    std::mutex mu;
+    int cus[kMaxDevices] = {};
+    template <class OptIn>
+    int get(OptIn&& opt_in, int* num_cu) {
+        int dev = 0;
+        IDN_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= kMaxDevices) return ::idn::fail(IDN_EUNSUPPORTED, "device index %d out of range", dev);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!cus[dev]) {
+            hipDeviceProp_t prop;
+            IDN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+            if (int e = opt_in()) return e;
+            cus[dev] = prop.multiProcessorCount;
+        }
+        *num_cu = cus[dev];
+        return IDN_OK;
+    }
+};
 
 // ---------------------------------------------------------------------------
 // optional per-launch timing of the MLP kernel (capi.hip); off by default

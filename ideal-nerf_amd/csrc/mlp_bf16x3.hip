@@ -480,20 +480,18 @@ int launch_mlp_bf16(const float* packed, const float* folded, const float* x, co
                     const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s) {
     constexpr int NW = IDN_PLAIN_WAVES;
     if (n_points <= 0) return IDN_OK;
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        IDN_HIP_CHECK(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        IDN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModeRays, NW>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModeX, NW>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModePts, NW>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        num_cu = prop.multiProcessorCount;
-    }
+    static LaunchSetup setup;
+    int num_cu = 0;
+    if (int e = setup.get([]() -> int {
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModeRays, NW>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModeX, NW>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModePts, NW>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            return IDN_OK;
+        }, &num_cu))
+        return e;
     const int64_t ntiles = (n_points + 32 * NW - 1) / (32 * NW);
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, nullptr, 0};
@@ -511,20 +509,18 @@ int launch_mlp_bf16(const float* packed, const float* folded, const float* x, co
 int launch_mlp_bf16x3(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
                       const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s) {
     if (n_points <= 0) return IDN_OK;
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        IDN_HIP_CHECK(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        IDN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModeRays>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModeX>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModePts>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        num_cu = prop.multiProcessorCount;
-    }
+    static LaunchSetup setup;
+    int num_cu = 0;
+    if (int e = setup.get([]() -> int {
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModeRays>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModeX>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModePts>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            return IDN_OK;
+        }, &num_cu))
+        return e;
     const int64_t ntiles = (n_points + 127) / 128;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, nullptr, 0};

@@ -343,22 +343,20 @@ int launch_mlp_f32(const float* packed, const float* folded, const float* x, con
                    const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s,
                    float* acts, int64_t p_pad) {
     if (n_points <= 0) return IDN_OK;
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        IDN_HIP_CHECK(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        IDN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        num_cu = prop.multiProcessorCount;
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeRays, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeX, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModePts, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeRays, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLdsTrain));
-    }
+    static LaunchSetup setup;
+    int num_cu = 0;
+    if (int e = setup.get([]() -> int {
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeRays, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeX, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModePts, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f32_kernel<kModeRays, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLdsTrain));
+            return IDN_OK;
+        }, &num_cu))
+        return e;
     const int64_t ntiles = (n_points + 127) / 128;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, acts, (long)p_pad};
