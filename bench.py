@@ -304,7 +304,10 @@ def main():
                          "frac": (ach / peak) if ach else None, "traffic": traffic,
                          "launches": k_n.value, "avg_launch_ms": (k_ms.value / k_n.value) if k_n.value else None,
                          "flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": (k_pts.value / k_n.value) if k_n.value else None,
-                         "kernel_time_share": (k_ms.value * 1e-3) / dt if dt > 0 else None},
+                         "kernel_time_share": (k_ms.value * 1e-3) / dt if dt > 0 else None,
+                         "note": "peak = dense MFMA peak at 2.4 GHz (guide).  Under sustained load the chip holds "
+                                 "1.8-2.0 GHz; an LDS-fed bf16 MFMA loop on random data tops out at 1.3-1.5 PFLOP/s of "
+                                 "issued MFMAs (tools/mfma_shape_ubench.hip, DESIGN.md section 3)"},
         }
         if world == 1 and args.precision != "f32" and not args.no_f32_mode:
             # the exact-fp32 mode of the same kernel family, measured after the timed region (2 frames)
