@@ -959,3 +959,43 @@ def test_facenerf_agg_golden(idn, dev, golden):
     assert rel_err(out, g["out"]) < 1e-5 and rel_err(out3, g["out"]) < 5e-5
     with pytest.raises(NotImplementedError):
         net(*args)
+
+
+def test_concurrent_host_threads_on_two_streams(idn, dev):
+    """under nn.DataParallel the reference calls forward from one host thread per replica.
+    Two threads, each on its own stream with its own network, must get what a serial call gets
+    (no shared mutable state in the library besides the per-device launch setup)."""
+    import threading
+    dims = oracle.facenerf_dims()
+    nets, xs, refs = [], [], []
+    rs = np.random.RandomState(3)
+    for seed in (21, 22):
+        net = idn.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76)
+        net.load_state_dict(oracle.xavier_facenerf_params(seed, dims))
+        net = net.to(dev)
+        net.precision = "bf16x3" if seed == 22 else "f32"
+        x = T(rs.uniform(-1, 1, size=(20000, 90)).astype(np.float32)).to(dev)
+        cond = [T(rs.standard_normal(k).astype(np.float32)).to(dev) for k in (64, 76, 32)]
+        with torch.no_grad():
+            refs.append(net(x, *cond).clone())
+        nets.append(net); xs.append((x, cond))
+    torch.cuda.synchronize()
+    outs, errs = [None, None], []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s), torch.no_grad():
+                for _ in range(5):
+                    o = nets[i](xs[i][0], *xs[i][1])
+                s.synchronize()
+            outs[i] = o
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
