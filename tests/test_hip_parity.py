@@ -999,3 +999,23 @@ def test_concurrent_host_threads_on_two_streams(idn, dev):
     assert not errs, errs
     for o, r in zip(outs, refs):
         assert torch.equal(o, r)
+
+
+@pytest.mark.parametrize("n_rays,S,Ni", [(37, 40, 72), (5, 17, 33), (130, 96, 160)])
+def test_render_unusual_sample_counts_vs_oracle(idn, dev, n_rays, S, Ni):
+    """Sample counts other than the paper's 64/128 and ragged ray counts, all three arithmetic
+    modes within their own budgets against the CPU oracle (which is pinned to the reference at 64/128)."""
+    dims, pc, pf, (pk_c, fold_c), (pk_f, fold_f) = _nets(idn, dev)
+    syn = oracle.synthetic_frame(32, 32, seed=4, dims=dims)
+    rays = idn.ops.frame_rays(syn["c2w"], 32, 32, syn["focal"], NEAR, FAR, device=dev)
+    sel = torch.from_numpy(np.random.RandomState(n_rays).choice(1024, n_rays, replace=False))
+    r = rays[sel.to(dev)].contiguous()
+    bc = syn["bc"].reshape(-1, 3)[sel].contiguous()
+    cond = (syn["aud"], syn["expr"], syn["latent"])
+    with torch.no_grad():
+        ref = oracle.render_rays(r.cpu(), bc, pc, pf, *cond, n_samples=S, n_importance=Ni, dims=dims)
+    t, u = torch.linspace(0.0, 1.0, S).to(dev), torch.linspace(0.0, 1.0, Ni).to(dev)
+    out = idn.ops.render_rays_fwd(r, bc.to(dev), pk_c, fold_c(*cond), pk_f, fold_f(*cond), t, u, Ni)
+    for k in ("rgb_map", "rgb0", "disp_map", "acc_map"):
+        assert rel_err(out[k], ref[k]) < RGB_TOL, k
+    assert abs_err(out["last_weight"], ref["last_weight"]) < W_TOL
