@@ -185,6 +185,36 @@ int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in,
                       int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s);
 
 // train.hip: backward of one render pass
+// ---------------------------------------------------------------------------
+// Backward delta chain (mlp_f32_bwd.hip): the transposed weights as a second fragment stream.
+// Stage s computes D_in^T = W_s^T . D_out^T for 32 points per wave, masks it with the saved
+// activation and keeps it in registers as the next stage's B operand.
+//   0 rgb_linear^T (K 3, padded)   1 views_linears.2^T   2 views_linears.1^T
+//   3 views_linears.0[:, :256]^T + alpha_linear^T as k-channel 128 (K 129, padded)
+//   4..10 pts_linears.7 .. pts_linears.1 ^T (pts_linears.5: its 256 hidden columns)
+// Stages 0-3 end at fragment 280; the stream is padded to 384 so that every 256-fragment trunk
+// stage starts on the same ring phase (one loop body serves them all).
+// ---------------------------------------------------------------------------
+constexpr int kBwdStages = 11;
+constexpr int kBwdNT[kBwdStages] = {4, 4, 4, 8, 8, 8, 8, 8, 8, 8, 8};
+constexpr int kBwdKG[kBwdStages] = {2, 16, 16, 18, 32, 32, 32, 32, 32, 32, 32};
+constexpr int kBwdHeadFrags = 280, kBwdTrunk0 = 384;
+constexpr int bwd_f0(int s) {
+    if (s >= 4) return kBwdTrunk0 + 256 * (s - 4);
+    int f = 0;
+    for (int i = 0; i < s; ++i) f += kBwdNT[i] * kBwdKG[i];
+    return f;
+}
+static_assert(bwd_f0(3) + kBwdNT[3] * kBwdKG[3] == kBwdHeadFrags, "head stages");
+constexpr int kBwdStreamFrags = kBwdTrunk0 + 7 * 256;   // 2176
+static_assert(kBwdStreamFrags % kSliceFrags == 0 && kBwdTrunk0 % kRingFrags == 0, "ring phase of the trunk stages");
+constexpr int kBwdNumSlices = kBwdStreamFrags / kSliceFrags;
+
+int launch_pack_f32_bwd(const idn_facenerf_params& p, float* packed_bwd, hipStream_t s);
+// d_rgb: [p_pad, 64] (cols 0..2 = d raw rgb), dv0: [p_pad, 256] (col 128 = d raw sigma; cols 0..127 are written),
+// acts: the forward's activation slab, dv2/dv1: [p_pad, 128], da[l]: [p_pad, 256] = delta of pts_linears.l
+int launch_delta_chain(const float* packed_bwd, const float* acts, int64_t p_pad, const float* d_rgb, float* dv0,
+                       float* dv2, float* dv1, float* const da[8], hipStream_t s);
 size_t bwd_workspace_bytes(int64_t n_points);
 int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, const float* aud, const float* expr,
                     const float* latent, const float* acts, const float* raw, const float* z, const float* rays,

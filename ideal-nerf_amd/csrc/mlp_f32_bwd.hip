@@ -1,0 +1,294 @@
+// Fused backward delta chain of FaceNeRF for the training step, fp32 MFMA (gfx950).
+//
+// Replaces the eleven per-layer "delta GEMMs" of the backward pass
+// (delta_{l-1} = (delta_l . W_l) (.) [a_{l-1} > 0]; loss.backward() through models/face_nerf.py:57-75,
+// NeRFs/HeadNeRF/train/audio_exp_nerf.py:534-552) by one kernel built like the forward one
+// (mlp_f32.hip): a wave owns 32 points, the TRANSPOSED weights are the streamed A operand, the
+// delta of one layer is the accumulator tile set that becomes the B operand of the next, and the
+// only HBM traffic per layer is the mask (the saved post-ReLU activation, read in accumulator
+// layout) and the delta itself, written row-major for the weight-gradient GEMMs (train.hip).
+// The separate GEMMs moved three P x 256 matrices per layer and sat on the HBM/MFMA ridge.
+#include "mlp_common.h"
+
+namespace idn {
+
+__device__ __forceinline__ f32x16 mfma_b(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// transposed stream: fragment (stage, tile t, k-group g), lane (i, h), element j =
+//   W_stage[k = 8g + 4h + j][col0 + n = 32t + i]      (zero beyond the valid rows / columns;
+//   stage 3 reads alpha_linear's weight as row 128)
+// ---------------------------------------------------------------------------
+struct BwdPackStage {
+    const float* w;      // forward weight [rows = out channels, ld]
+    const float* extra;  // optional extra row (alpha_linear) at k == extra_at
+    int ld, col0, rows, cols, extra_at;
+};
+struct BwdPackDesc {
+    BwdPackStage st[kBwdStages];
+};
+__global__ void pack_f32_bwd_kernel(BwdPackDesc d, float4* out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= kBwdStreamFrags * 64) return;
+    const int f = gid >> 6, lane = gid & 63;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int s = -1;
+    for (int i = 0; i < kBwdStages; ++i)
+        if (f >= bwd_f0(i) && f < bwd_f0(i) + kBwdNT[i] * kBwdKG[i]) s = i;
+    if (s >= 0) {
+        const BwdPackStage& S = d.st[s];
+        const int rel = f - bwd_f0(s), t = rel / kBwdKG[s], g = rel - t * kBwdKG[s];
+        const int n = 32 * t + (lane & 31);
+        for (int j = 0; j < 4; ++j) {
+            const int k = 8 * g + 4 * (lane >> 5) + j;
+            if (n < S.cols) {
+                if (k < S.rows) v[j] = S.w[(long)k * S.ld + S.col0 + n];
+                else if (S.extra && k == S.extra_at) v[j] = S.extra[n];
+            }
+        }
+    }
+    out[gid] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+int launch_pack_f32_bwd(const idn_facenerf_params& p, float* packed_bwd, hipStream_t s) {
+    const int C = p.dim_aud + p.dim_expr + p.dim_latent;
+    BwdPackDesc d;
+    d.st[0] = {p.rgb_w, nullptr, IDN_W / 2, 0, 3, IDN_W / 2, -1};
+    d.st[1] = {p.views_w[2], nullptr, IDN_W / 2, 0, IDN_W / 2, IDN_W / 2, -1};
+    d.st[2] = {p.views_w[1], nullptr, IDN_W / 2, 0, IDN_W / 2, IDN_W / 2, -1};
+    d.st[3] = {p.views_w[0], p.alpha_w, IDN_W + IDN_VIEWS_CH + p.dim_expr, 0, IDN_W / 2, IDN_W, kSigmaChannel};
+    for (int l = 7; l >= 1; --l) {
+        BwdPackStage& S = d.st[4 + (7 - l)];
+        S = {p.pts_w[l], nullptr, l == 5 ? IDN_PTS_CH + C + IDN_W : IDN_W, l == 5 ? IDN_PTS_CH + C : 0, IDN_W, IDN_W, -1};
+    }
+    const int total = kBwdStreamFrags * 64;
+    hipLaunchKernelGGL(pack_f32_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d, reinterpret_cast<float4*>(packed_bwd));
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------
+struct DeltaArgs {
+    const float* wstream;
+    const float* acts;
+    long p_pad;
+    const float* d_rgb;   // [p_pad, 64]
+    float* dv0;           // [p_pad, 256]
+    float* dv2;           // [p_pad, 128]
+    float* dv1;           // [p_pad, 128]
+    float* da[8];
+};
+
+// One stage's MFMAs (the forward's pair-step driver with this stream's fragment positions).
+template <int F0, int NT, int KG, bool LAST, class BGet, class Side>
+__device__ __forceinline__ void run_stage(f32x16 (&out)[NT], BGet&& bget, WStream& ws, FragReader& fr, Side&& side) {
+    constexpr int STEPS = KG / 2, NP = NT * STEPS;
+    static_assert(KG % 2 == 0 && F0 % 2 == 0, "fragments are consumed in pairs");
+    if constexpr (F0 % kSliceFrags == 0) {
+        ws.open_slice();
+        fr.pref0 = fr.template issue<F0>();
+        fr.pref1 = fr.template issue<F0 + 1>();
+    }
+    f32x4 a0 = fr.pref0, a1 = fr.pref1;
+    static_for<NP>([&](auto PI) {
+        constexpr int pi = decltype(PI)::value;
+        constexpr int t = pi / STEPS, s = pi % STEPS, g0 = 2 * s, g1 = g0 + 1;
+        constexpr int f = F0 + 2 * pi;
+        constexpr bool next_crosses = ((f + 2) % kSliceFrags == 0);
+        f32x4 n0 = a0, n1 = a1;
+        if constexpr (!next_crosses && !(LAST && pi + 1 == NP)) {
+            n0 = fr.template issue<f + 2>();
+            n1 = fr.template issue<f + 3>();
+            FragReader::retire<2>(a0, a1);
+        } else {
+            FragReader::retire<0>(a0, a1);
+        }
+        ws.template step_piece<f>();
+        side(ic<t>{}, ic<s>{}, ic<0>{});
+        out[t] = mfma_b(a0.x, bget(ic<g0>{}, ic<0>{}), out[t]);
+        out[t] = mfma_b(a0.y, bget(ic<g0>{}, ic<1>{}), out[t]);
+        out[t] = mfma_b(a0.z, bget(ic<g0>{}, ic<2>{}), out[t]);
+        out[t] = mfma_b(a0.w, bget(ic<g0>{}, ic<3>{}), out[t]);
+        out[t] = mfma_b(a1.x, bget(ic<g1>{}, ic<0>{}), out[t]);
+        out[t] = mfma_b(a1.y, bget(ic<g1>{}, ic<1>{}), out[t]);
+        out[t] = mfma_b(a1.z, bget(ic<g1>{}, ic<2>{}), out[t]);
+        out[t] = mfma_b(a1.w, bget(ic<g1>{}, ic<3>{}), out[t]);
+        if constexpr (next_crosses && pi + 1 < NP) {
+            ws.open_slice();
+            n0 = fr.template issue<f + 2>();
+            n1 = fr.template issue<f + 3>();
+        }
+        a0 = n0;
+        a1 = n1;
+    });
+    fr.pref0 = a0;
+    fr.pref1 = a1;
+}
+
+// The mask of tile t (the saved activation's 16 values this lane's accumulator registers
+// correspond to) is loaded when tile t starts and applied to the finished tile t-1 in the
+// shadow of tile t's MFMAs; the last tile's mask is applied after the stage.
+template <int NT, int STEPS>
+struct MaskSide {
+    f32x16* out;
+    f32x4 (*mbuf)[4];          // [2][4]: double-buffered masks, 4 quads of 4 channels
+    const float* mrow;         // activation row of this lane's point + 4h
+    template <int T>
+    __device__ __forceinline__ void load(ic<T>) const {
+        static_for<4>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            mbuf[T & 1][q] = *reinterpret_cast<const f32x4*>(mrow + 32 * T + 8 * q);
+        });
+    }
+    template <int T>
+    __device__ __forceinline__ void apply(ic<T>) const {
+        static_for<16>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            out[T][r] = mbuf[T & 1][r >> 2][r & 3] > 0.0f ? out[T][r] : 0.0f;
+        });
+    }
+    template <int T, int S, int H>
+    __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {
+        constexpr int kApplyStep = STEPS > 1 ? 1 : 0;   // a one-step stage (rgb_linear^T) applies before it reloads
+        if constexpr (S == kApplyStep && T > 0) apply(ic<T - 1>{});
+        if constexpr (S == 0) load(ic<T>{});
+    }
+};
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&t)[NT]) {
+    static_for<NT>([&](auto T) {
+        static_for<16>([&](auto R) { t[decltype(T)::value][decltype(R)::value] = 0.0f; });
+    });
+}
+
+// rows of a row-major [p_pad, ld] matrix <- NT accumulator tiles (see save_tiles in mlp_f32.hip)
+template <int NT>
+__device__ __forceinline__ void store_tiles(const f32x16 (&t)[NT], float* dst, int ld, long p0, float* stage, int lane) {
+    const int m = lane & 31, h = lane >> 5;
+    static_for<NT>([&](auto T) {
+        constexpr int tt = decltype(T)::value;
+        static_for<16>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            stage[m * kStagePitch + (r & 3) + 8 * (r >> 2) + 4 * h] = t[tt][r];
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        static_for<16>([&](auto RR) {
+            constexpr int rr = decltype(RR)::value;
+            const int row = 2 * rr + h;
+            dst[(p0 + row) * ld + 32 * tt + m] = stage[row * kStagePitch + m];
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    });
+}
+
+constexpr int kDeltaLds = kRingFrags * kFragBytes + 4 * kStageFloats * 4;
+
+__global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    float* stage = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes) + wave * kStageFloats;
+
+    Diag dg;
+    WStream ws;
+    ws.dg = &dg;
+    ws.init(a.wstream, kBwdNumSlices, ring, tid, wave);
+    FragReader fr;
+    fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
+    fr.addr1 = fr.addr0 + 64 * kFragBytes;
+    const long ntiles = a.p_pad >> 7;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long p0 = tile * 128 + wave * 32;
+        const long P = p0 + m;
+        const float* arow = a.acts + 4 * h;  // + act_off(i) * p_pad + P * width(i): per stage below
+        auto act_row = [&](int idx, int width) { return arow + (long)act_off(idx) * a.p_pad + P * width; };
+        // d raw of this lane's point: rgb in k-channels 0..2 (lane half 0), sigma in k-channel 128
+        const f32x4 drgb = *reinterpret_cast<const f32x4*>(a.d_rgb + P * 64);
+        const float dsig = a.dv0[P * 256 + kSigmaChannel];
+
+        f32x16 A[8], B[8];
+        f32x4 mbuf[2][4];
+        auto tiles_get = [](f32x16* arr) {
+            return [arr](auto G, auto J) {
+                constexpr int g = decltype(G)::value, j = decltype(J)::value;
+                return arr[g >> 2][(g & 3) * 4 + j];
+            };
+        };
+        // one stage: zero accumulators, MFMAs with the mask in their shadow, last tile's mask, store
+        auto stage_run = [&](auto Sc, auto F0c, auto LASTc, auto& out, auto&& bget, const float* mrow, float* dst, int ld) {
+            constexpr int S = decltype(Sc)::value, F0 = decltype(F0c)::value;
+            constexpr int NT = kBwdNT[S], KG = kBwdKG[S];
+            zero_tiles<NT>(out);
+            const MaskSide<NT, KG / 2> side{&out[0], mbuf, mrow};
+            run_stage<F0, NT, KG, decltype(LASTc)::value != 0>(out, bget, ws, fr, side);
+            side.apply(ic<NT - 1>{});
+            store_tiles<NT>(out, dst, ld, p0, stage, lane);
+        };
+        f32x16(&A4)[4] = reinterpret_cast<f32x16(&)[4]>(A);
+        f32x16(&B4)[4] = reinterpret_cast<f32x16(&)[4]>(B);
+
+        // 0: rgb_linear^T : d rgb (3) -> delta of views_linears.2, masked by its output v3
+        stage_run(ic<0>{}, ic<bwd_f0(0)>{}, ic<0>{}, A4,
+                  [&](auto G, auto J) {
+                      constexpr int g = decltype(G)::value, j = decltype(J)::value;
+                      if constexpr (g == 0 && j < 3) return h ? 0.0f : drgb[j];
+                      else return 0.0f;
+                  },
+                  act_row(kActV1 + 2, 128), a.dv2, 128);
+        // 1: views_linears.2^T -> delta of views_linears.1 (mask v2);  2: views_linears.1^T -> views_linears.0 (mask v1)
+        stage_run(ic<1>{}, ic<bwd_f0(1)>{}, ic<0>{}, B4, tiles_get(A), act_row(kActV1 + 1, 128), a.dv1, 128);
+        stage_run(ic<2>{}, ic<bwd_f0(2)>{}, ic<0>{}, A4, tiles_get(B), act_row(kActV1 + 0, 128), a.dv0, 256);
+        // 3: views_linears.0[:, :256]^T + alpha_linear^T (d sigma as k-channel 128) -> delta of pts_linears.7 (mask a8)
+        stage_run(ic<3>{}, ic<bwd_f0(3)>{}, ic<1>{}, B,
+                  [&](auto G, auto J) {
+                      constexpr int g = decltype(G)::value, j = decltype(J)::value;
+                      if constexpr (g < 16) return A[g >> 2][(g & 3) * 4 + j];
+                      else if constexpr (g == 16 && j == 0) return h ? 0.0f : dsig;
+                      else return 0.0f;
+                  },
+                  act_row(kActA1 + 7, 256), a.da[7], 256);
+        finish_pass<kBwdHeadFrags, kBwdTrunk0>(ws);   // walk the padding up to the trunk stages
+        // 4..9: pts_linears.7 .. .2 ^T in pairs (B -> A -> B), then pts_linears.1^T (last of the pass)
+#pragma unroll 1
+        for (int l = 7; l >= 3; l -= 2) {
+            stage_run(ic<4>{}, ic<bwd_f0(4)>{}, ic<0>{}, A, tiles_get(B), act_row(kActA1 + l - 1, 256), a.da[l - 1], 256);
+            stage_run(ic<5>{}, ic<bwd_f0(5)>{}, ic<0>{}, B, tiles_get(A), act_row(kActA1 + l - 2, 256), a.da[l - 2], 256);
+        }
+        stage_run(ic<10>{}, ic<bwd_f0(10)>{}, ic<1>{}, A, tiles_get(B), act_row(kActA1 + 0, 256), a.da[0], 256);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+}
+
+int launch_delta_chain(const float* packed_bwd, const float* acts, int64_t p_pad, const float* d_rgb, float* dv0,
+                       float* dv2, float* dv1, float* const da[8], hipStream_t s) {
+    if (p_pad <= 0) return IDN_OK;
+    if (p_pad % 128) return fail(IDN_EINVAL, "delta chain: p_pad %lld is not a multiple of 128", (long long)p_pad);
+    static LaunchSetup setup;
+    int num_cu = 0;
+    if (int e = setup.get([]() -> int {
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&delta_chain_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kDeltaLds));
+            return IDN_OK;
+        }, &num_cu))
+        return e;
+    const int64_t ntiles = p_pad / 128;
+    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
+    DeltaArgs a{packed_bwd, acts, (long)p_pad, d_rgb, dv0, dv2, dv1, {}};
+    for (int l = 0; l < 8; ++l) a.da[l] = da[l];
+    hipLaunchKernelGGL(delta_chain_kernel, dim3(grid), dim3(256), kDeltaLds, s, a);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+}  // namespace idn

@@ -421,7 +421,7 @@ constexpr int kMaxSplits = 256;
 constexpr int kColsumBlocks = 256;
 
 struct BwdWs {
-    float *dA[2], *dV[2], *dV0, *dRGB, *part, *cpart, *dbtmp;
+    float *dA[8], *dV[2], *dV0, *dRGB, *part, *cpart, *dbtmp, *wbwd;
     size_t bytes;
 };
 static BwdWs carve_bwd(char* base, int64_t p_pad) {
@@ -432,8 +432,7 @@ static BwdWs carve_bwd(char* base, int64_t p_pad) {
         off += al256(floats * 4);
         return p;
     };
-    w.dA[0] = take((size_t)p_pad * 256);
-    w.dA[1] = take((size_t)p_pad * 256);
+    for (int l = 0; l < 8; ++l) w.dA[l] = take((size_t)p_pad * 256);  // delta of pts_linears.l (pre-activation)
     w.dV[0] = take((size_t)p_pad * 128);
     w.dV[1] = take((size_t)p_pad * 128);
     w.dV0 = take((size_t)p_pad * 256);
@@ -441,6 +440,7 @@ static BwdWs carve_bwd(char* base, int64_t p_pad) {
     w.part = take((size_t)kMaxSplits * 256 * 256);
     w.cpart = take((size_t)kColsumBlocks * 256);
     w.dbtmp = take(1024);
+    w.wbwd = take((size_t)kBwdStreamFrags * kFragFloats);               // transposed weight stream of the delta chain
     w.bytes = off;
     return w;
 }
@@ -544,18 +544,17 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
         IDN_HIP_CHECK(hipGetLastError());
     }
 #define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
-    // rgb_linear: dW[3,128] = dRGB^T v3 ; db ; delta(views2 pre-act) = (dRGB . Wrgb) (.) [v3 > 0]
+    // All pre-activation deltas in one fused pass over the points (mlp_f32_bwd.hip): dV[0] = delta of
+    // views_linears.2, dV[1] = views_linears.1, dV0[:, :128] = views_linears.0 (col 128 = d sigma), dA[l] = pts_linears.l
+    TRY(launch_pack_f32_bwd(p, w.wbwd, s));
+    TRY(launch_delta_chain(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
+    // weight and bias gradients: dW_l = delta_l^T a_{l-1} (contraction over the points), db_l = column sums
     TRY(run_tn(w.dRGB, 64, 64, v_l(3), 128, 128, Pp, w.part, gr.rgb_w, 128, 3, 128, s));
     TRY(run_colsum(w.dRGB, 64, Pp, 3, w.cpart, gr.rgb_b, s));
-    TRY(run_nn(w.dRGB, 64, p.rgb_w, 128, 3, nullptr, -1, w.dV[0], 128, v_l(3), 128, Pp, 128, 64, s));
-    // views_linears.2
     TRY(run_tn(w.dV[0], 128, 128, v_l(2), 128, 128, Pp, w.part, gr.views_w[2], 128, 128, 128, s));
     TRY(run_colsum(w.dV[0], 128, Pp, 128, w.cpart, gr.views_b[2], s));
-    TRY(run_nn(w.dV[0], 128, p.views_w[2], 128, 128, nullptr, -1, w.dV[1], 128, v_l(2), 128, Pp, 128, 128, s));
-    // views_linears.1 ; its input delta lands in columns 0..127 of dV0 (column 128 already holds d sigma)
     TRY(run_tn(w.dV[1], 128, 128, v_l(1), 128, 128, Pp, w.part, gr.views_w[1], 128, 128, 128, s));
     TRY(run_colsum(w.dV[1], 128, Pp, 128, w.cpart, gr.views_b[1], s));
-    TRY(run_nn(w.dV[1], 128, p.views_w[1], 128, 128, nullptr, -1, w.dV0, 256, v_l(1), 128, Pp, 128, 128, s));
     // views_linears.0 (+ alpha_linear as channel 128); inputs [a8 | dirPE | expr(folded)]
     {
         int splits = 0;
@@ -568,11 +567,8 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
         IDN_HIP_CHECK(hipMemcpyAsync(gr.views_b[0], w.dbtmp, 128 * 4, hipMemcpyDeviceToDevice, s));
         IDN_HIP_CHECK(hipMemcpyAsync(gr.alpha_b, w.dbtmp + kSigmaChannel, 4, hipMemcpyDeviceToDevice, s));
     }
-    float* cur = w.dA[0];
-    float* nxt = w.dA[1];
-    TRY(run_nn(w.dV0, 256, p.views_w[0], ldv, 128, p.alpha_w, kSigmaChannel, cur, 256, a_l(8), 256, Pp, 256, 256, s));
-    // trunk: cur = delta of pts_linears.l's pre-activation
     for (int l = 7; l >= 1; --l) {
+        const float* cur = w.dA[l];
         if (l == 5) {
             TRY(run_tn(cur, 256, 256, a_l(5), 256, 256, Pp, w.part, gr.pts_w[5] + IDN_PTS_CH + C, ld5, 256, 256, s));
             TRY(run_tn(cur, 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[5], ld5, 256, IDN_PTS_CH, s));
@@ -580,12 +576,9 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
             TRY(run_tn(cur, 256, 256, a_l(l), 256, 256, Pp, w.part, gr.pts_w[l], 256, 256, 256, s));
         }
         TRY(run_colsum(cur, 256, Pp, 256, w.cpart, gr.pts_b[l], s));
-        const float* B = (l == 5) ? p.pts_w[5] + IDN_PTS_CH + C : p.pts_w[l];
-        TRY(run_nn(cur, 256, B, l == 5 ? ld5 : 256, 256, nullptr, -1, nxt, 256, a_l(l), 256, Pp, 256, 256, s));
-        float* t = cur; cur = nxt; nxt = t;
     }
-    TRY(run_tn(cur, 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[0], ld0, 256, IDN_PTS_CH, s));
-    TRY(run_colsum(cur, 256, Pp, 256, w.cpart, gr.pts_b[0], s));
+    TRY(run_tn(w.dA[0], 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[0], ld0, 256, IDN_PTS_CH, s));
+    TRY(run_colsum(w.dA[0], 256, Pp, 256, w.cpart, gr.pts_b[0], s));
 #undef TRY
     {
         FoldBwdArgs f{p, aud, expr, latent, gr.pts_b[0], gr.pts_b[5], gr.views_b[0], gr.pts_w[0], gr.pts_w[5],
