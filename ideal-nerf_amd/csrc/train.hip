@@ -3,7 +3,7 @@
 // FaceNeRF and the per-frame conditioning).  gfx950, fp32 MFMA.
 //
 //   composite_bwd     d(rgb_map, rgb_fg, last_weight, acc) -> d raw           (one wave per ray)
-//   gemm_nn           delta_{l-1} = (delta_l . W_l) (.) [a_{l-1} > 0]          (rows = points)
+//   delta chain       all delta_l = (delta_{l+1} . W_{l+1}) (.) [a_l > 0] in one fused kernel (mlp_f32_bwd.hip)
 //   gemm_tn           dW_l = delta_l^T . a_{l-1}, contraction over points, split over workgroups
 //   reduce_partials   sums the per-split dW blocks into the gradient tensors
 //   colsum            db_l = sum_p delta_l
@@ -22,78 +22,6 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ int d_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
-
-// ---------------------------------------------------------------------------
-// NN GEMM: C[M x N] = (A[M x K] . B[K x N]) masked.  M = points (multiple of 128),
-// N multiple of 64, K multiple of 32.  B is a window of a weight matrix: rows >= b_rows
-// read as zero, except row `extra_at` which reads `extra` (alpha_linear riding in views0).
-// ---------------------------------------------------------------------------
-struct NNArgs {
-    const float* A; int lda;
-    const float* B; int ldb; int b_rows; const float* extra; int extra_at;
-    float* C; int ldc;
-    const float* mask; int ldm;
-    int K;
-    int m_tiles, n_blocks;
-};
-constexpr int kNNPitchA = 36;  // 128 x 32 A tile, ds_read_b128 conflict-free (pitch = 4 mod 32 dwords)
-
-__global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[128 * kNNPitchA];
-    __shared__ __attribute__((aligned(16))) float Bs[32 * 64];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int i = lane & 31, hh = lane >> 5;
-    // XCD-aware tile order: workgroup b runs on XCD b % 8, so the n_blocks column blocks that read
-    // the same 128 rows of A are given consecutive slots of ONE XCD and share them through its L2
-    // (with the row-major order A came from HBM once per column block: 4x the algorithmic bytes).
-    const int slot = blockIdx.x >> 3;
-    const int mt = (slot / g.n_blocks) * 8 + (blockIdx.x & 7);
-    if (mt >= g.m_tiles) return;
-    const long m0 = (long)mt * 128;
-    const int n0 = (slot % g.n_blocks) * 64;
-    f32x16 acc[2];
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-
-    for (int k0 = 0; k0 < g.K; k0 += 32) {
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + 256 * q, row = idx >> 3, ch = idx & 7;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(g.A + (m0 + row) * g.lda + k0 + ch * 4);
-            *reinterpret_cast<f32x4*>(&As[row * kNNPitchA + ch * 4]) = v;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int idx = tid + 256 * q, row = idx >> 6, col = idx & 63;
-            const int kk = k0 + row;
-            float v = 0.f;
-            if (kk < g.b_rows) v = g.B[(long)kk * g.ldb + n0 + col];
-            else if (g.extra && kk == g.extra_at) v = g.extra[n0 + col];
-            Bs[row * 64 + col] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[(32 * w + i) * kNNPitchA + 8 * gg + 4 * hh]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = 8 * gg + 4 * hh + j;
-                acc[0] = mfma32(a4[j], Bs[c * 64 + i], acc[0]);
-                acc[1] = mfma32(a4[j], Bs[c * 64 + 32 + i], acc[1]);
-            }
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long row = m0 + 32 * w + d_row(r, hh);
-            const int col = n0 + 32 * nt + i;
-            float v = acc[nt][r];
-            if (g.mask) v = g.mask[row * g.ldm + col] > 0.f ? v : 0.f;
-            g.C[row * g.ldc + col] = v;
-        }
-}
 
 // ---------------------------------------------------------------------------
 // TN GEMM: part[split][n][k] = sum_{p in split} A[p][n0+n] * B[p][k0+k]
@@ -448,15 +376,6 @@ static BwdWs carve_bwd(char* base, int64_t p_pad) {
 size_t bwd_workspace_bytes(int64_t n_points) {
     const int64_t p_pad = (n_points + 127) / 128 * 128;
     return carve_bwd(nullptr, p_pad).bytes;
-}
-
-static int run_nn(const float* A, int lda, const float* B, int ldb, int b_rows, const float* extra, int extra_at,
-                  float* C, int ldc, const float* mask, int ldm, int64_t M, int N, int K, hipStream_t s) {
-    const int m_tiles = (int)(M / 128), n_blocks = N / 64;
-    NNArgs g{A, lda, B, ldb, b_rows, extra, extra_at, C, ldc, mask, ldm, K, m_tiles, n_blocks};
-    hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)((m_tiles + 7) / 8 * 8 * n_blocks)), dim3(256), 0, s, g);
-    IDN_HIP_CHECK(hipGetLastError());
-    return IDN_OK;
 }
 
 // part[split][N][K] = A[:, :N]^T . B[:, :K] over point splits; returns the split count

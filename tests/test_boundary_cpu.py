@@ -219,9 +219,9 @@ def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
         return str(out)
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
-        files = list(ex.map(compile_s, ["mlp_f32", "mlp_bf16x3"]))
+        files = list(ex.map(compile_s, ["mlp_f32", "mlp_bf16x3", "mlp_f32_bwd"]))
     for f in files:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), f, "mlp_"],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), f, ""],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
         assert "0 suspicious touches" in r.stdout
