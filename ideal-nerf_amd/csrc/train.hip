@@ -36,12 +36,17 @@ struct TNArgs {
     int chunks_per_split;      // 32-row chunks per split
 };
 
+// The two 32-row chunk tiles are double-buffered in LDS and filled by LDS-DMA (a chunk row is
+// contiguous in global memory and in the tile, so one wave instruction moves 1 KiB of it): the
+// loads of chunk c+1 are in flight while chunk c is multiplied, one barrier per chunk.  (Single
+// buffered, every chunk paid its global-load latency: 70 % of the fp32 MFMA peak.)
 template <int NTW, int KTW>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     constexpr int BN = 64 * NTW, BK = 64 * KTW;
-    __shared__ __attribute__((aligned(16))) float As[32 * BN];
-    __shared__ __attribute__((aligned(16))) float Bs[32 * BK];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int kTileFloats = 32 * (BN + BK);            // one chunk: A tile then B tile
+    extern __shared__ __attribute__((aligned(16))) float tn_smem[];  // 2 * kTileFloats
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hh = lane >> 5;
     const int wr = w >> 1, wc = w & 1;
     const int n0 = blockIdx.x * BN, k0 = blockIdx.y * BK;
@@ -57,22 +62,33 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     long c_end = c_begin + g.chunks_per_split;
     const long c_total = g.P / 32;
     if (c_end > c_total) c_end = c_total;
-    for (long c = c_begin; c < c_end; ++c) {
+
+    // wave w moves every 4th 1-KiB piece of a tile: piece q holds float4 elements 64 q .. 64 q + 63
+    auto fill = [&](long c, int buf) {
         const long p0 = c * 32;
-        __syncthreads();
+        float* As = tn_smem + buf * kTileFloats;
+        float* Bs = As + 32 * BN;
 #pragma unroll
-        for (int q = 0; q < BN / 32; ++q) {
-            const int idx = tid + 256 * q, row = idx / (BN / 4), ch = idx % (BN / 4);
-            *reinterpret_cast<f32x4*>(&As[row * BN + ch * 4]) =
-                *reinterpret_cast<const f32x4*>(g.A + (p0 + row) * g.lda + n0 + ch * 4);
+        for (int q = 0; q < BN / 32; ++q) {      // 32 * BN / 4 float4 = BN / 8 pieces, 4 waves -> BN / 32 each
+            const int piece = 4 * q + w, e = piece * 64 + lane, row = e / (BN / 4), c4 = e % (BN / 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (p0 + row) * g.lda + n0 + 4 * c4),
+                                             (__attribute__((address_space(3))) void*)(As + piece * 256), 16, 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < BK / 32; ++q) {
-            const int idx = tid + 256 * q, row = idx / (BK / 4), ch = idx % (BK / 4);
-            *reinterpret_cast<f32x4*>(&Bs[row * BK + ch * 4]) =
-                *reinterpret_cast<const f32x4*>(g.B + (p0 + row) * g.ldb + k0 + ch * 4);
+            const int piece = 4 * q + w, e = piece * 64 + lane, row = e / (BK / 4), c4 = e % (BK / 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.B + (p0 + row) * g.ldb + k0 + 4 * c4),
+                                             (__attribute__((address_space(3))) void*)(Bs + piece * 256), 16, 0, 0);
         }
-        __syncthreads();
+    };
+    if (c_begin < c_end) fill(c_begin, 0);
+    for (long c = c_begin; c < c_end; ++c) {
+        const int buf = (int)((c - c_begin) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk c have landed
+        __syncthreads();                                   // everyone's have; everyone is done with the other buffer
+        if (c + 1 < c_end) fill(c + 1, buf ^ 1);
+        const float* As = tn_smem + buf * kTileFloats;
+        const float* Bs = As + 32 * BN;
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
             const int prow = 2 * s + hh;
@@ -396,10 +412,21 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
     splits = (int)((chunks + cps - 1) / cps);
     TNArgs g{A, lda, B, ldb, part, N, K, (long)P, cps};
     const dim3 grid(bx, by, splits), block(256);
-    if (ntw == 4 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, s, g);
-    else if (ntw == 4 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), grid, block, 0, s, g);
-    else if (ntw == 2 && ktw == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_tn_kernel<1, 2>), grid, block, 0, s, g);
+    const size_t lds = 2 * 32 * (size_t)(64 * ntw + 64 * ktw) * 4;
+    static LaunchSetup setup;
+    int num_cu = 0;
+    if (int e = setup.get([]() -> int {
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<4, 4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 512 * 4));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<4, 1>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 320 * 4));
+            return IDN_OK;
+        }, &num_cu))
+        return e;
+    if (ntw == 4 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, lds, s, g);
+    else if (ntw == 4 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), grid, block, lds, s, g);
+    else if (ntw == 2 && ktw == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, lds, s, g);
+    else hipLaunchKernelGGL((gemm_tn_kernel<1, 2>), grid, block, lds, s, g);
     IDN_HIP_CHECK(hipGetLastError());
     *splits_out = splits;
     return IDN_OK;
