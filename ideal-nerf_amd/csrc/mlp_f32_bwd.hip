@@ -129,14 +129,26 @@ __device__ __forceinline__ void run_stage(f32x16 (&out)[NT], BGet&& bget, WStrea
     fr.pref1 = a1;
 }
 
-// The mask of tile t (the saved activation's 16 values this lane's accumulator registers
-// correspond to) is loaded when tile t starts and applied to the finished tile t-1 in the
-// shadow of tile t's MFMAs; the last tile's mask is applied after the stage.
+// In the shadow of tile t's MFMAs (pair-steps 0 ..): the mask of tile t is loaded (step 0), the
+// finished tile t-1 is masked (step 1), scattered into the wave's LDS patch (step 2) and written
+// out as row segments: the four row values of quad q are READ from the patch at step 3 + q and
+// STORED at step 4 + q.  The patch reads are inline asm like the fragment reads: LDS returns in
+// order, so the pair-step's counted `lgkmcnt(2)` (FragReader::retire) has covered them by the time
+// they are stored, and the compiler never waits `lgkmcnt(0)` for them (it did, sixteen exposed LDS
+// round trips per tile, when these were plain loads).  The last tile of a stage, and every tile
+// of a stage too short for this schedule, is finished after the stage (finish()).
 template <int NT, int STEPS>
 struct MaskSide {
+    static constexpr bool kShadowStore = STEPS >= 8;
     f32x16* out;
     f32x4 (*mbuf)[4];          // [2][4]: double-buffered masks, 4 quads of 4 channels
     const float* mrow;         // activation row of this lane's point + 4h
+    float* dst;                // delta matrix, row p0 of this wave, column m of tile 0
+    long ld;
+    float* stage;              // this wave's 32 x 33 transpose patch
+    float* rb;                 // [4] row values in flight between their read and their store
+    uint32_t raddr;            // LDS byte address of patch[h][m]
+    int m, h;
     template <int T>
     __device__ __forceinline__ void load(ic<T>) const {
         static_for<4>([&](auto Q) {
@@ -151,11 +163,54 @@ struct MaskSide {
             out[T][r] = mbuf[T & 1][r >> 2][r & 3] > 0.0f ? out[T][r] : 0.0f;
         });
     }
+    template <int T>
+    __device__ __forceinline__ void scatter(ic<T>) const {
+        static_for<16>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            stage[m * kStagePitch + (r & 3) + 8 * (r >> 2) + 4 * h] = out[T][r];
+        });
+        asm volatile("" ::: "memory");   // the asm reads below come after these writes (LDS executes a wave's operations in order)
+    }
+    template <int Q>
+    __device__ __forceinline__ void rows_read(ic<Q>) const {   // rows 2 (4Q + i) + h, i = 0..3
+        static_for<4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rb[i]) : "v"(raddr), "n"(2 * (4 * Q + i) * kStagePitch * 4) : "memory");
+        });
+    }
+    template <int T, int Q>
+    __device__ __forceinline__ void rows_store(ic<T>, ic<Q>) const {
+        asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));   // not before the wait that precedes this call
+        static_for<4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            dst[(2 * (4 * Q + i) + h) * ld + 32 * T] = rb[i];
+        });
+    }
+    template <int T>
+    __device__ __forceinline__ void flush_tile(ic<T>) const {   // outside the pair-step pipeline: explicit waits
+        scatter(ic<T>{});
+        static_for<4>([&](auto Q) {
+            rows_read(Q);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3])::"memory");
+            rows_store(ic<T>{}, Q);
+        });
+    }
+    // after the stage: whatever the shadow schedule did not cover
+    __device__ __forceinline__ void finish() const {
+        apply(ic<NT - 1>{});
+        if constexpr (kShadowStore) flush_tile(ic<NT - 1>{});
+        else static_for<NT>([&](auto T) { flush_tile(T); });
+    }
     template <int T, int S, int H>
     __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {
         constexpr int kApplyStep = STEPS > 1 ? 1 : 0;   // a one-step stage (rgb_linear^T) applies before it reloads
         if constexpr (S == kApplyStep && T > 0) apply(ic<T - 1>{});
         if constexpr (S == 0) load(ic<T>{});
+        if constexpr (kShadowStore && T > 0) {
+            if constexpr (S == 2) scatter(ic<T - 1>{});
+            if constexpr (S >= 4 && S <= 7) rows_store(ic<T - 1>{}, ic<S - 4>{});
+            if constexpr (S >= 3 && S <= 6) rows_read(ic<S - 3>{});
+        }
     }
 };
 
@@ -163,28 +218,6 @@ template <int NT>
 __device__ __forceinline__ void zero_tiles(f32x16 (&t)[NT]) {
     static_for<NT>([&](auto T) {
         static_for<16>([&](auto R) { t[decltype(T)::value][decltype(R)::value] = 0.0f; });
-    });
-}
-
-// rows of a row-major [p_pad, ld] matrix <- NT accumulator tiles (see save_tiles in mlp_f32.hip)
-template <int NT>
-__device__ __forceinline__ void store_tiles(const f32x16 (&t)[NT], float* dst, int ld, long p0, float* stage, int lane) {
-    const int m = lane & 31, h = lane >> 5;
-    static_for<NT>([&](auto T) {
-        constexpr int tt = decltype(T)::value;
-        static_for<16>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            stage[m * kStagePitch + (r & 3) + 8 * (r >> 2) + 4 * h] = t[tt][r];
-        });
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        static_for<16>([&](auto RR) {
-            constexpr int rr = decltype(RR)::value;
-            const int row = 2 * rr + h;
-            dst[(p0 + row) * ld + 32 * tt + m] = stage[row * kStagePitch + m];
-        });
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     });
 }
 
@@ -206,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
     fr.addr1 = fr.addr0 + 64 * kFragBytes;
     const long ntiles = a.p_pad >> 7;
+    const uint32_t raddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)stage + (h * kStagePitch + m) * 4;
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long p0 = tile * 128 + wave * 32;
@@ -218,6 +252,7 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
 
         f32x16 A[8], B[8];
         f32x4 mbuf[2][4];
+        float rb[4];
         auto tiles_get = [](f32x16* arr) {
             return [arr](auto G, auto J) {
                 constexpr int g = decltype(G)::value, j = decltype(J)::value;
@@ -229,10 +264,9 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
             constexpr int S = decltype(Sc)::value, F0 = decltype(F0c)::value;
             constexpr int NT = kBwdNT[S], KG = kBwdKG[S];
             zero_tiles<NT>(out);
-            const MaskSide<NT, KG / 2> side{&out[0], mbuf, mrow};
+            const MaskSide<NT, KG / 2> side{&out[0], mbuf, mrow, dst + p0 * ld + m, (long)ld, stage, rb, raddr, m, h};
             run_stage<F0, NT, KG, decltype(LASTc)::value != 0>(out, bget, ws, fr, side);
-            side.apply(ic<NT - 1>{});
-            store_tiles<NT>(out, dst, ld, p0, stage, lane);
+            side.finish();
         };
         f32x16(&A4)[4] = reinterpret_cast<f32x16(&)[4]>(A);
         f32x16(&B4)[4] = reinterpret_cast<f32x16(&)[4]>(B);

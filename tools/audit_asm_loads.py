@@ -60,7 +60,7 @@ def audit(lines, name):
             over = regs(code.split()[1].rstrip(','))          # a later writer owns the register again
             mfma_dst = [(r - over, i) for r, i in mfma_dst]
         if in_asm:
-            if code.startswith('ds_read_b128'):
+            if code.startswith('ds_read_b'):
                 dst = code.split()[1].rstrip(',')
                 inflight.append((regs(dst), no))
             elif code.startswith('s_waitcnt'):
