@@ -381,6 +381,11 @@ __device__ __forceinline__ void point_of(const PointIn& in, float (&p)[3], float
     }
 }
 
+// buffer descriptor over the 32 rows (LD floats each) a wave writes of a row-major matrix
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(float* first_row, int ld) {
+    return __builtin_amdgcn_make_buffer_rsrc(first_row, 0, 32 * ld * 4, 0x00020000);
+}
+
 constexpr int kMlpLds = kRingFrags * kFragBytes + kBiasFloats * 4;
 constexpr int kStagePitch = 33;                       // 32x32 transpose tile, conflict-free
 constexpr int kStageFloats = 32 * kStagePitch;

@@ -104,31 +104,76 @@ struct LayerSide {
         }
     }
 };
-// Training: write NT post-ReLU accumulator tiles (channel = register, point = lane) as rows
-// of a row-major [p_pad, ld] matrix: transpose each 32x32 tile through a per-wave LDS patch
-// so that every global store instruction writes two full 128-byte row segments.
-template <int NT>
-__device__ __forceinline__ void save_tiles(const f32x16 (&t)[NT], float* dst, int ld, long p0, long n_points,
-                                           float* stage, int lane) {
-    const int m = lane & 31, h = lane >> 5;
-    static_for<NT>([&](auto T) {
-        constexpr int tt = decltype(T)::value;
+// Training: the NT post-ReLU accumulator tiles of a layer (channel = register, point = lane) are
+// written as rows of a row-major [p_pad, ld] matrix, in the shadow of the MFMAs: tile t-1 is ReLU'd
+// at pair-step 0 of tile t, scattered into a per-wave 32x33 LDS patch (step 1) and written out as
+// two full 128-byte row segments per store, the four values of quad q being READ from the patch at
+// step 2 + q and STORED at step 3 + q.  The patch reads are inline asm like the fragment reads: LDS
+// returns in order, so the pair-step's counted wait has covered them by the time they are stored
+// (as plain loads each one was followed by `lgkmcnt(0)`: sixteen exposed round trips per tile).
+// Every row of the p_pad-row slab is written -- padding rows repeat the last point -- because the
+// weight-gradient GEMMs contract over all p_pad rows (their deltas are zero, but 0 x garbage is not).
+template <int NT, int STEPS, int LD>
+struct SaveSide {
+    static constexpr bool kShadowStore = STEPS >= 8;
+    f32x16* out;
+    __amdgpu_buffer_rsrc_t rsrc;   // this wave's 32 rows of the activation matrix (LD floats per row)
+    uint32_t voff;                 // byte offset of [row h][column m]
+    float* stage;     // this wave's transpose patch
+    float* rb;        // [4] row values in flight between their read and their store
+    uint32_t raddr;   // LDS byte address of patch[h][m]
+    int m, h;
+    template <int T>
+    __device__ __forceinline__ void scatter(ic<T>) const {
         static_for<16>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            stage[m * kStagePitch + (r & 3) + 8 * (r >> 2) + 4 * h] = t[tt][r];
+            stage[m * kStagePitch + (r & 3) + 8 * (r >> 2) + 4 * h] = out[T][r];
         });
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        static_for<16>([&](auto RR) {
-            constexpr int rr = decltype(RR)::value;
-            const int row = 2 * rr + h;
-            const float v = stage[row * kStagePitch + m];
-            if (p0 + row < n_points) dst[(p0 + row) * ld + 32 * tt + m] = v;
+        asm volatile("" ::: "memory");   // the asm reads below come after these writes (a wave's LDS operations execute in order)
+    }
+    template <int Q>
+    __device__ __forceinline__ void rows_read(ic<Q>) const {   // rows 2 (4Q + i) + h, i = 0..3
+        static_for<4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rb[i]) : "v"(raddr), "n"(2 * (4 * Q + i) * kStagePitch * 4) : "memory");
         });
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    });
-}
+    }
+    template <int T, int Q>
+    __device__ __forceinline__ void rows_store(ic<T>, ic<Q>) const {
+        asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));   // not before the wait that precedes this call
+        static_for<4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            // descriptor + one lane-offset VGPR + a compile-time scalar offset: no per-row address arithmetic or registers
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rb[i]), rsrc, voff, (2 * (4 * Q + i) * LD + 32 * T) * 4, 0);
+        });
+    }
+    template <int T>
+    __device__ __forceinline__ void flush_tile(ic<T>) const {   // outside the pair-step pipeline: explicit waits
+        scatter(ic<T>{});
+        static_for<4>([&](auto Q) {
+            rows_read(Q);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3])::"memory");
+            rows_store(ic<T>{}, Q);
+        });
+    }
+    __device__ __forceinline__ void finish() const {   // after the layer: what the shadow schedule did not cover
+        relu_regs<0, 16>(out[NT - 1]);
+        if constexpr (kShadowStore) flush_tile(ic<NT - 1>{});
+        else {
+            static_for<NT - 1>([&](auto T) { relu_regs<0, 16>(out[decltype(T)::value]); });
+            static_for<NT>([&](auto T) { flush_tile(T); });
+        }
+    }
+    template <int T, int S, int H>
+    __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {
+        if constexpr (kShadowStore && T > 0 && H == 0) {
+            if constexpr (S == 0) relu_regs<0, 16>(out[T - 1]);
+            if constexpr (S == 1) scatter(ic<T - 1>{});
+            if constexpr (S >= 3 && S <= 6) rows_store(ic<T - 1>{}, ic<S - 3>{});
+            if constexpr (S >= 2 && S <= 5) rows_read(ic<S - 2>{});
+        }
+    }
+};
 
 template <int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
@@ -136,6 +181,8 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
     char* ring = smem;
     float* bias_s = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes);
     float* stage = reinterpret_cast<float*>(smem + kMlpLds) + (threadIdx.x >> 6) * kStageFloats;  // SAVE only
+    const uint32_t raddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)stage +
+                           (((threadIdx.x & 63) >> 5) * kStagePitch + (threadIdx.x & 31)) * 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -217,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         }
         const long p0 = tile * 128 + wave * 32;  // first point of this wave
         if constexpr (SAVE) {
-            if (valid) {
+            {   // every row of the slab, padding included (see SaveSide)
                 float* x0 = a.acts + act_off(kActX0) * a.p_pad + P * 64 + 4 * h;
                 float* dr = a.acts + act_off(kActDir) * a.p_pad + P * 64 + 4 * h;
                 static_for<8>([&](auto G) {
@@ -238,6 +285,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         // Two sets of eight 32x32 tiles take turns as a layer's input (B operands) and output
         // (accumulators); a finished layer's output is ReLU'd in place and read by the next.
         f32x16 A[8], B[8], V[5];
+        float rb[4];
         auto pe_get = [&](auto G, auto J) { return pe[decltype(G)::value][decltype(J)::value]; };
         auto tiles_get = [](f32x16* arr) {
             return [arr](auto G, auto J) {
@@ -258,13 +306,14 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
             else bias_tile(out[0], bias_l);
             DIAG_END(dg, kDgBoundary);
             if constexpr (SAVE) {
-                run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, NoSide{});
-                DIAG_BEGIN(dg);
-                if (save_idx >= 0) {  // hidden layer: ReLU + record
-                    relu_tiles<NT>(out);
-                    save_tiles<NT>(out, a.acts + (long)act_off(save_idx) * a.p_pad, 32 * NT, p0, a.n_points, stage, lane);
+                if (save_idx >= 0) {  // hidden layer: ReLU + record, in the MFMA shadow
+                    const SaveSide<NT, KG / 2, 32 * NT> side{&out[0], rows_rsrc(a.acts + (long)act_off(save_idx) * a.p_pad + p0 * (32 * NT), 32 * NT),
+                                                             (uint32_t)((h * (32 * NT) + m) * 4), stage, rb, raddr, m, h};
+                    run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, side);
+                    side.finish();
+                } else {
+                    run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, NoSide{});
                 }
-                DIAG_END(dg, kDgBoundary);
             } else {
                 run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, LayerSide<NT, KG / 2, DEFER>{&out[0], deferred, bias_l});
             }
@@ -304,7 +353,9 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
             DIAG_BEGIN(dg);
             f32x16(&V4)[4] = reinterpret_cast<f32x16(&)[4]>(V);
             relu_tiles<4>(V4);
-            save_tiles<4>(V4, a.acts + (long)act_off(kActV1) * a.p_pad, 128, p0, a.n_points, stage, lane);
+            const SaveSide<4, 1, 128> side{&V4[0], rows_rsrc(a.acts + (long)act_off(kActV1) * a.p_pad + p0 * 128, 128),
+                                           (uint32_t)((h * 128 + m) * 4), stage, rb, raddr, m, h};
+            static_for<4>([&](auto T) { side.flush_tile(T); });
             DIAG_END(dg, kDgBoundary);
         }
         // ---- views_linears.1, .2 : 128 -> 128   (V -> A[0..3] -> V[0..3])

@@ -137,14 +137,14 @@ __device__ __forceinline__ void run_stage(f32x16 (&out)[NT], BGet&& bget, WStrea
 // they are stored, and the compiler never waits `lgkmcnt(0)` for them (it did, sixteen exposed LDS
 // round trips per tile, when these were plain loads).  The last tile of a stage, and every tile
 // of a stage too short for this schedule, is finished after the stage (finish()).
-template <int NT, int STEPS>
+template <int NT, int STEPS, int LD>
 struct MaskSide {
     static constexpr bool kShadowStore = STEPS >= 8;
     f32x16* out;
     f32x4 (*mbuf)[4];          // [2][4]: double-buffered masks, 4 quads of 4 channels
     const float* mrow;         // activation row of this lane's point + 4h
-    float* dst;                // delta matrix, row p0 of this wave, column m of tile 0
-    long ld;
+    __amdgpu_buffer_rsrc_t rsrc;  // this wave's 32 rows of the delta matrix (LD floats per row)
+    uint32_t voff;             // byte offset of [row h][column m]
     float* stage;              // this wave's 32 x 33 transpose patch
     float* rb;                 // [4] row values in flight between their read and their store
     uint32_t raddr;            // LDS byte address of patch[h][m]
@@ -183,7 +183,7 @@ struct MaskSide {
         asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));   // not before the wait that precedes this call
         static_for<4>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            dst[(2 * (4 * Q + i) + h) * ld + 32 * T] = rb[i];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rb[i]), rsrc, voff, (2 * (4 * Q + i) * LD + 32 * T) * 4, 0);
         });
     }
     template <int T>
@@ -260,11 +260,12 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
             };
         };
         // one stage: zero accumulators, MFMAs with the mask in their shadow, last tile's mask, store
-        auto stage_run = [&](auto Sc, auto F0c, auto LASTc, auto& out, auto&& bget, const float* mrow, float* dst, int ld) {
+        auto stage_run = [&](auto Sc, auto F0c, auto LASTc, auto LDc, auto& out, auto&& bget, const float* mrow, float* dst) {
             constexpr int S = decltype(Sc)::value, F0 = decltype(F0c)::value;
             constexpr int NT = kBwdNT[S], KG = kBwdKG[S];
             zero_tiles<NT>(out);
-            const MaskSide<NT, KG / 2> side{&out[0], mbuf, mrow, dst + p0 * ld + m, (long)ld, stage, rb, raddr, m, h};
+            constexpr int LD = decltype(LDc)::value;
+            const MaskSide<NT, KG / 2, LD> side{&out[0], mbuf, mrow, rows_rsrc(dst + p0 * LD, LD), (uint32_t)((h * LD + m) * 4), stage, rb, raddr, m, h};
             run_stage<F0, NT, KG, decltype(LASTc)::value != 0>(out, bget, ws, fr, side);
             side.finish();
         };
@@ -272,33 +273,33 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
         f32x16(&B4)[4] = reinterpret_cast<f32x16(&)[4]>(B);
 
         // 0: rgb_linear^T : d rgb (3) -> delta of views_linears.2, masked by its output v3
-        stage_run(ic<0>{}, ic<bwd_f0(0)>{}, ic<0>{}, A4,
+        stage_run(ic<0>{}, ic<bwd_f0(0)>{}, ic<0>{}, ic<128>{}, A4,
                   [&](auto G, auto J) {
                       constexpr int g = decltype(G)::value, j = decltype(J)::value;
                       if constexpr (g == 0 && j < 3) return h ? 0.0f : drgb[j];
                       else return 0.0f;
                   },
-                  act_row(kActV1 + 2, 128), a.dv2, 128);
+                  act_row(kActV1 + 2, 128), a.dv2);
         // 1: views_linears.2^T -> delta of views_linears.1 (mask v2);  2: views_linears.1^T -> views_linears.0 (mask v1)
-        stage_run(ic<1>{}, ic<bwd_f0(1)>{}, ic<0>{}, B4, tiles_get(A), act_row(kActV1 + 1, 128), a.dv1, 128);
-        stage_run(ic<2>{}, ic<bwd_f0(2)>{}, ic<0>{}, A4, tiles_get(B), act_row(kActV1 + 0, 128), a.dv0, 256);
+        stage_run(ic<1>{}, ic<bwd_f0(1)>{}, ic<0>{}, ic<128>{}, B4, tiles_get(A), act_row(kActV1 + 1, 128), a.dv1);
+        stage_run(ic<2>{}, ic<bwd_f0(2)>{}, ic<0>{}, ic<256>{}, A4, tiles_get(B), act_row(kActV1 + 0, 128), a.dv0);
         // 3: views_linears.0[:, :256]^T + alpha_linear^T (d sigma as k-channel 128) -> delta of pts_linears.7 (mask a8)
-        stage_run(ic<3>{}, ic<bwd_f0(3)>{}, ic<1>{}, B,
+        stage_run(ic<3>{}, ic<bwd_f0(3)>{}, ic<1>{}, ic<256>{}, B,
                   [&](auto G, auto J) {
                       constexpr int g = decltype(G)::value, j = decltype(J)::value;
                       if constexpr (g < 16) return A[g >> 2][(g & 3) * 4 + j];
                       else if constexpr (g == 16 && j == 0) return h ? 0.0f : dsig;
                       else return 0.0f;
                   },
-                  act_row(kActA1 + 7, 256), a.da[7], 256);
+                  act_row(kActA1 + 7, 256), a.da[7]);
         finish_pass<kBwdHeadFrags, kBwdTrunk0>(ws);   // walk the padding up to the trunk stages
         // 4..9: pts_linears.7 .. .2 ^T in pairs (B -> A -> B), then pts_linears.1^T (last of the pass)
 #pragma unroll 1
         for (int l = 7; l >= 3; l -= 2) {
-            stage_run(ic<4>{}, ic<bwd_f0(4)>{}, ic<0>{}, A, tiles_get(B), act_row(kActA1 + l - 1, 256), a.da[l - 1], 256);
-            stage_run(ic<5>{}, ic<bwd_f0(5)>{}, ic<0>{}, B, tiles_get(A), act_row(kActA1 + l - 2, 256), a.da[l - 2], 256);
+            stage_run(ic<4>{}, ic<bwd_f0(4)>{}, ic<0>{}, ic<256>{}, A, tiles_get(B), act_row(kActA1 + l - 1, 256), a.da[l - 1]);
+            stage_run(ic<5>{}, ic<bwd_f0(5)>{}, ic<0>{}, ic<256>{}, B, tiles_get(A), act_row(kActA1 + l - 2, 256), a.da[l - 2]);
         }
-        stage_run(ic<10>{}, ic<bwd_f0(10)>{}, ic<1>{}, A, tiles_get(B), act_row(kActA1 + 0, 256), a.da[0], 256);
+        stage_run(ic<10>{}, ic<bwd_f0(10)>{}, ic<1>{}, ic<256>{}, A, tiles_get(B), act_row(kActA1 + 0, 256), a.da[0]);
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();

@@ -1019,3 +1019,28 @@ def test_render_unusual_sample_counts_vs_oracle(idn, dev, n_rays, S, Ni):
     for k in ("rgb_map", "rgb0", "disp_map", "acc_map"):
         assert rel_err(out[k], ref[k]) < RGB_TOL, k
     assert abs_err(out["last_weight"], ref["last_weight"]) < W_TOL
+
+
+def test_train_forward_defines_every_row_of_the_activation_slab(idn, dev):
+    """The weight-gradient GEMMs contract over all p_pad rows of the saved activations, so the padding
+    rows of a ragged pass must hold finite numbers (their deltas are zero, but 0 x NaN is not): fill
+    the slab with NaN, run the training forward on 37 x 5 points, and nothing non-finite may remain."""
+    import ctypes as C
+    lib = idn._lib.load()
+    dims = oracle.facenerf_dims()
+    net = idn.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76)
+    net.load_state_dict(oracle.xavier_facenerf_params(7, dims))
+    net = net.to(dev)
+    syn = oracle.synthetic_frame(32, 32, seed=1, dims=dims)
+    rays = idn.ops.frame_rays(syn["c2w"], 32, 32, syn["focal"], NEAR, FAR, device=dev)[:37].contiguous()
+    n, S = 37, 5
+    z = idn.ops.coarse_depths(rays, torch.linspace(0.0, 1.0, S).to(dev))
+    folded = net.folded_bias(syn["aud"].to(dev), syn["expr"].to(dev), syn["latent"].to(dev))
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=dev)
+    acts = torch.full((lib.idealnerf_train_acts_floats(n * S),), float("nan"), dtype=torch.float32, device=dev)
+    rc = lib.idealnerf_query_rays_train_fwd(net.packed_weights("f32").data_ptr(), folded.data_ptr(), 0, rays.data_ptr(),
+                                            z.data_ptr(), n, S, raw.data_ptr(), acts.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.idealnerf_last_error()
+    assert acts.numel() == 256 * 2560   # 185 points -> p_pad = 256 rows of 2560 columns
+    assert bool(torch.isfinite(acts).all()) and bool(torch.isfinite(raw).all())
