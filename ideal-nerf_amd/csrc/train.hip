@@ -6,7 +6,7 @@
 //   delta chain       all delta_l = (delta_{l+1} . W_{l+1}) (.) [a_l > 0] in one fused kernel (mlp_f32_bwd.hip)
 //   gemm_tn           dW_l = delta_l^T . a_{l-1}, contraction over points, split over workgroups
 //   reduce_partials   sums the per-split dW blocks into the gradient tensors
-//   colsum            db_l = sum_p delta_l
+//   (db_l = sum_p delta_l comes out of gemm_tn's pass over delta_l)
 //   fold_bwd          conditioning columns of W0 / W5 / Wv0 and d aud, d latent
 //
 // Activations come from the training variant of the MLP kernel as row-major matrices
@@ -34,6 +34,7 @@ struct TNArgs {
     int N, K;
     long P;                    // rows (multiple of 32)
     int chunks_per_split;      // 32-row chunks per split
+    float* cpart;              // optional [splits][N]: column sums of A (the bias gradient), from the k-block-0 workgroups
 };
 
 // The two 32-row chunk tiles are double-buffered in LDS and filled by LDS-DMA (a chunk row is
@@ -62,6 +63,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     long c_end = c_begin + g.chunks_per_split;
     const long c_total = g.P / 32;
     if (c_end > c_total) c_end = c_total;
+    const bool do_colsum = g.cpart != nullptr && blockIdx.y == 0 && tid < BN;
+    float csum = 0.0f;
 
     // wave w moves every 4th 1-KiB piece of a tile: piece q holds float4 elements 64 q .. 64 q + 63
     auto fill = [&](long c, int buf) {
@@ -89,6 +92,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
         if (c + 1 < c_end) fill(c + 1, buf ^ 1);
         const float* As = tn_smem + buf * kTileFloats;
         const float* Bs = As + 32 * BN;
+        if (do_colsum) {   // the delta tile is in LDS anyway: its column sums are the bias gradient (1 % more VALU)
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) csum += As[r * BN + tid];
+        }
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
             const int prow = 2 * s + hh;
@@ -103,6 +110,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
                 for (int y = 0; y < KTW; ++y) acc[x][y] = mfma32(a[x], b[y], acc[x][y]);
         }
     }
+    if (do_colsum) g.cpart[(long)split * g.N + n0 + tid] = csum;
     float* out = g.part + (long)split * g.N * g.K;
 #pragma unroll
     for (int x = 0; x < NTW; ++x)
@@ -136,45 +144,6 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     red[q][o] = s;
     __syncthreads();
     if (q == 0 && live) out[(long)n * ldo + k] = (float)(((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
-}
-
-// part[blk][c] = sum over the block's rows of A[p][c]   (bias gradients: HBM-bound, one pass over A)
-// A block owns rows_per_block consecutive rows; its 256 threads are CQ column quads x 256/CQ row
-// lanes, each summing every (256/CQ)-th row of its four columns in fp64 (16-byte loads, eight in
-// flight); the row lanes are then added in a fixed order, so the result is deterministic.
-template <int CQ>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, long P, int C,
-                                                     long rows_per_block, float* __restrict__ part) {
-    constexpr int RL = 256 / CQ;
-    __shared__ double red[RL][CQ * 4];
-    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
-    const long p0 = (long)blockIdx.x * rows_per_block;
-    long p1 = p0 + rows_per_block;
-    if (p1 > P) p1 = P;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    const int c0 = 4 * cq;
-    if (c0 + 3 < C && (lda & 3) == 0) {
-#pragma unroll 8
-        for (long p = p0 + rl; p < p1; p += RL) {
-            const float4 v = *reinterpret_cast<const float4*>(A + p * lda + c0);
-            s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
-        }
-    } else if (c0 < C) {
-        for (long p = p0 + rl; p < p1; p += RL) {
-            const float* r = A + p * lda + c0;
-            s0 += (double)r[0];
-            if (c0 + 1 < C) s1 += (double)r[1];
-            if (c0 + 2 < C) s2 += (double)r[2];
-            if (c0 + 3 < C) s3 += (double)r[3];
-        }
-    }
-    red[rl][c0 + 0] = s0; red[rl][c0 + 1] = s1; red[rl][c0 + 2] = s2; red[rl][c0 + 3] = s3;
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double t = 0.0;
-        for (int r = 0; r < RL; ++r) t += red[r][c];
-        part[(long)blockIdx.x * C + c] = (float)t;
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -362,7 +331,7 @@ __global__ void fold_bwd_kernel(FoldBwdArgs d) {
 // ---------------------------------------------------------------------------
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kMaxSplits = 256;
-constexpr int kColsumBlocks = 256;
+constexpr int kColsumBlocks = 256;   // rows of the column-sum partial buffer (>= kMaxSplits)
 
 struct BwdWs {
     float *dA[8], *dV[2], *dV0, *dRGB, *part, *cpart, *dbtmp, *wbwd;
@@ -396,7 +365,7 @@ size_t bwd_workspace_bytes(int64_t n_points) {
 
 // part[split][N][K] = A[:, :N]^T . B[:, :K] over point splits; returns the split count
 static int run_tn_partials(const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part,
-                           int* splits_out, hipStream_t s) {
+                           int* splits_out, hipStream_t s, float* cpart = nullptr) {
     int ntw, ktw;
     if (N == 256 && K == 256) { ntw = 4; ktw = 4; }
     else if (N == 256 && K == 64) { ntw = 4; ktw = 1; }
@@ -410,7 +379,7 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
     if (splits < 1) splits = 1;
     const int cps = (int)((chunks + splits - 1) / splits);
     splits = (int)((chunks + cps - 1) / cps);
-    TNArgs g{A, lda, B, ldb, part, N, K, (long)P, cps};
+    TNArgs g{A, lda, B, ldb, part, N, K, (long)P, cps, cpart};
     const dim3 grid(bx, by, splits), block(256);
     const size_t lds = 2 * 32 * (size_t)(64 * ntw + 64 * ktw) * 4;
     static LaunchSetup setup;
@@ -440,23 +409,14 @@ static int run_reduce(const float* part, int splits, int N, int K, int row0, flo
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }
+// out = A^T B (rows x cols of it); db (optional, `db_cols` entries) = column sums of A, from the same pass over A
 static int run_tn(const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part, float* out,
-                  int ldo, int rows, int cols, hipStream_t s) {
+                  int ldo, int rows, int cols, hipStream_t s, float* cpart = nullptr, float* db = nullptr, int db_cols = 0) {
     int splits = 0;
-    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, &splits, s)) return e;
+    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, &splits, s, db ? cpart : nullptr)) return e;
+    if (db)
+        if (int e = run_reduce(cpart, splits, 1, N, 0, db, N, 1, db_cols, s)) return e;
     return run_reduce(part, splits, N, K, 0, out, ldo, rows, cols, s);
-}
-
-static int run_colsum(const float* A, int lda, int64_t P, int C, float* cpart, float* out, hipStream_t s) {
-    const long rpb = (P + kColsumBlocks - 1) / kColsumBlocks;
-    const int blocks = (int)((P + rpb - 1) / rpb);
-    if (C <= 4) hipLaunchKernelGGL(colsum_kernel<1>, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
-    else if (C <= 128) hipLaunchKernelGGL(colsum_kernel<32>, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
-    else hipLaunchKernelGGL(colsum_kernel<64>, dim3(blocks), dim3(256), 0, s, A, lda, (long)P, C, rpb, cpart);
-    IDN_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, s, cpart, blocks, 1, C, out, C, 1, C);
-    IDN_HIP_CHECK(hipGetLastError());
-    return IDN_OK;
 }
 
 int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, const float* aud, const float* expr,
@@ -495,36 +455,31 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
     TRY(launch_pack_f32_bwd(p, w.wbwd, s));
     TRY(launch_delta_chain(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
     // weight and bias gradients: dW_l = delta_l^T a_{l-1} (contraction over the points), db_l = column sums
-    TRY(run_tn(w.dRGB, 64, 64, v_l(3), 128, 128, Pp, w.part, gr.rgb_w, 128, 3, 128, s));
-    TRY(run_colsum(w.dRGB, 64, Pp, 3, w.cpart, gr.rgb_b, s));
-    TRY(run_tn(w.dV[0], 128, 128, v_l(2), 128, 128, Pp, w.part, gr.views_w[2], 128, 128, 128, s));
-    TRY(run_colsum(w.dV[0], 128, Pp, 128, w.cpart, gr.views_b[2], s));
-    TRY(run_tn(w.dV[1], 128, 128, v_l(1), 128, 128, Pp, w.part, gr.views_w[1], 128, 128, 128, s));
-    TRY(run_colsum(w.dV[1], 128, Pp, 128, w.cpart, gr.views_b[1], s));
+    TRY(run_tn(w.dRGB, 64, 64, v_l(3), 128, 128, Pp, w.part, gr.rgb_w, 128, 3, 128, s, w.cpart, gr.rgb_b, 3));
+    TRY(run_tn(w.dV[0], 128, 128, v_l(2), 128, 128, Pp, w.part, gr.views_w[2], 128, 128, 128, s, w.cpart, gr.views_b[2], 128));
+    TRY(run_tn(w.dV[1], 128, 128, v_l(1), 128, 128, Pp, w.part, gr.views_w[1], 128, 128, 128, s, w.cpart, gr.views_b[1], 128));
     // views_linears.0 (+ alpha_linear as channel 128); inputs [a8 | dirPE | expr(folded)]
     {
         int splits = 0;
-        TRY(run_tn_partials(w.dV0, 256, 256, a_l(8), 256, 256, Pp, w.part, &splits, s));
+        TRY(run_tn_partials(w.dV0, 256, 256, a_l(8), 256, 256, Pp, w.part, &splits, s, w.cpart));
+        TRY(run_reduce(w.cpart, splits, 1, 256, 0, w.dbtmp, 256, 1, 256, s));
         TRY(run_reduce(w.part, splits, 256, 256, 0, gr.views_w[0], ldv, 128, 256, s));
         TRY(run_reduce(w.part, splits, 256, 256, kSigmaChannel, gr.alpha_w, 256, 1, 256, s));
         TRY(run_tn_partials(w.dV0, 256, 256, act(kActDir), 64, 64, Pp, w.part, &splits, s));
         TRY(run_reduce(w.part, splits, 256, 64, 0, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH, s));
-        TRY(run_colsum(w.dV0, 256, Pp, 256, w.cpart, w.dbtmp, s));
         IDN_HIP_CHECK(hipMemcpyAsync(gr.views_b[0], w.dbtmp, 128 * 4, hipMemcpyDeviceToDevice, s));
         IDN_HIP_CHECK(hipMemcpyAsync(gr.alpha_b, w.dbtmp + kSigmaChannel, 4, hipMemcpyDeviceToDevice, s));
     }
     for (int l = 7; l >= 1; --l) {
         const float* cur = w.dA[l];
         if (l == 5) {
-            TRY(run_tn(cur, 256, 256, a_l(5), 256, 256, Pp, w.part, gr.pts_w[5] + IDN_PTS_CH + C, ld5, 256, 256, s));
+            TRY(run_tn(cur, 256, 256, a_l(5), 256, 256, Pp, w.part, gr.pts_w[5] + IDN_PTS_CH + C, ld5, 256, 256, s, w.cpart, gr.pts_b[5], 256));
             TRY(run_tn(cur, 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[5], ld5, 256, IDN_PTS_CH, s));
         } else {
-            TRY(run_tn(cur, 256, 256, a_l(l), 256, 256, Pp, w.part, gr.pts_w[l], 256, 256, 256, s));
+            TRY(run_tn(cur, 256, 256, a_l(l), 256, 256, Pp, w.part, gr.pts_w[l], 256, 256, 256, s, w.cpart, gr.pts_b[l], 256));
         }
-        TRY(run_colsum(cur, 256, Pp, 256, w.cpart, gr.pts_b[l], s));
     }
-    TRY(run_tn(w.dA[0], 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[0], ld0, 256, IDN_PTS_CH, s));
-    TRY(run_colsum(w.dA[0], 256, Pp, 256, w.cpart, gr.pts_b[0], s));
+    TRY(run_tn(w.dA[0], 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[0], ld0, 256, IDN_PTS_CH, s, w.cpart, gr.pts_b[0], 256));
 #undef TRY
     {
         FoldBwdArgs f{p, aud, expr, latent, gr.pts_b[0], gr.pts_b[5], gr.views_b[0], gr.pts_w[0], gr.pts_w[5],
