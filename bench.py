@@ -214,10 +214,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
+    # IDN_FORCE_DEVICE / IDN_DIST_BACKEND exist only to rehearse the N>1 code path on a one-GPU box
+    # (two ranks sharing device 0 over gloo); the driver's runs use one GPU per rank over RCCL.
+    if "IDN_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["IDN_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("IDN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import idealnerf_amd
     from idealnerf_amd import ops, parallel, synthetic
