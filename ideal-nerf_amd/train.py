@@ -34,6 +34,9 @@ def train_step(network, optimizer, data, latent_codes, global_step, dataset_size
     latent_code_loss = torch.norm(latent_code) * network.args.lc_weight
     loss = loss + latent_code_loss * 10
     loss.backward()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        from .parallel import average_gradients   # one bucketed all-reduce; a no-op for a single rank
+        average_gradients([p for g in optimizer.param_groups for p in g['params']])
     optimizer.step()
     new_lrate = decayed_lr(lrate, lrate_decay, global_step)
     for group in optimizer.param_groups:

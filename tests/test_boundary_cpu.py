@@ -182,6 +182,42 @@ def _gloo_worker(rank, world, H, port, ok):
         dist.destroy_process_group()
 
 
+def _gloo_grad_worker(rank, world, port, ok):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from idealnerf_amd.parallel import average_gradients
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2))]
+        ps[0].grad = torch.full((3, 5), float(rank + 1))
+        ps[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
+        if rank == 0:
+            ps[2].grad = torch.ones(2, 2)            # rank 1 never touched this parameter
+        average_gradients(ps)
+        good = (torch.allclose(ps[0].grad, torch.full((3, 5), 1.5)) and
+                torch.allclose(ps[1].grad, torch.arange(7, dtype=torch.float32) * 1.5) and
+                torch.allclose(ps[2].grad, torch.full((2, 2), 0.5)))
+        ok[rank] = int(good)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_average_gradients_gloo_two_ranks():
+    """Data-parallel training: one bucketed all-reduce averages every gradient, missing ones count as zero."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ok = ctx.Array("i", [0, 0])
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_grad_worker, args=(r, 2, port, ok)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert list(ok) == [1, 1]
+
+
 @pytest.mark.parametrize("H", [8, 9])
 def test_gather_rows_gloo_two_ranks(H):
     """N>1 path on CPU: two ranks render disjoint row bands and all-gather them (even and
