@@ -191,12 +191,15 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-f32-mode", action="store_true", help="skip the exact-fp32 side measurement (profiling runs)")
+    ap.add_argument("--no-f32-mode", "--no-side-mode", dest="no_f32_mode", action="store_true",
+                    help="skip the side measurement of the other arithmetic mode (profiling runs)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default=os.environ.get("IDN_PRECISION", "bf16x3"),
-                    help="arithmetic of the MLP contraction; f32 and bf16x3 meet the 1e-4 RGB parity bar "
-                         "(tests/test_hip_parity.py), bf16x3 is 3.4x faster and the default; bf16 (plain, ~1e-2) "
-                         "only meets BASELINE config 5's PSNR criterion and is never the headline number")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default=os.environ.get("IDN_PRECISION", "f32"),
+                    help="arithmetic of the MLP contraction.  f32 (default, the headline line): exact fp32 MFMA chains, "
+                         "RGB within 1e-6..1e-5 of the reference.  bf16x3: three bf16 MFMAs per product, 3.4x faster, "
+                         "within the 1e-4 RGB budget on the reference's golden frame and this scene, but sharp scenes "
+                         "amplify its 1.5e-5 through the importance sampling (DESIGN.md section 3) -- measured beside "
+                         "the headline as `bf16x3_mode`.  bf16 (plain, ~1e-2): BASELINE config 5's PSNR criterion only")
     ap.add_argument("--workload", choices=["frame", "train", "torso"], default="frame",
                     help="frame = BASELINE configs[1] (default, the headline metric); train = configs[2] train step; "
                          "torso = configs[4] head+torso composite frames, plain bf16, frame-parallel")
@@ -317,29 +320,36 @@ def main():
                                  "1.8-2.0 GHz; an LDS-fed bf16 MFMA loop on random data tops out at 1.3-1.5 PFLOP/s of "
                                  "issued MFMAs (tools/mfma_shape_ubench.hip, DESIGN.md section 3)"},
         }
-        if world == 1 and args.precision != "f32" and not args.no_f32_mode:
-            # the exact-fp32 mode of the same kernel family, measured after the timed region (2 frames)
-            coarse.precision = fine.precision = "f32"
-            p32c, p32f = coarse.packed_weights(), fine.packed_weights()
-            def step32():
+        if world == 1 and not args.no_f32_mode:
+            # the other arithmetic mode of the same kernel family on the same box and scene, measured after
+            # the timed region (2 frames): bf16x3 beside the fp32 headline, fp32 beside anything else
+            other = "bf16x3" if args.precision == "f32" else "f32"
+            coarse.precision = fine.precision = other
+            pko_c, pko_f = coarse.packed_weights(), fine.packed_weights()
+            code = coarse.prec_code
+            def step_other():
                 rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0, device=dev)
-                return ops.render_rays_fwd(rays, bc, p32c, coarse.folded_bias(aud, expr, latent), p32f,
-                                           fine.folded_bias(aud, expr, latent), t_vals, u, Ni, precision=0)
+                return ops.render_rays_fwd(rays, bc, pko_c, coarse.folded_bias(aud, expr, latent), pko_f,
+                                           fine.folded_bias(aud, expr, latent), t_vals, u, Ni, precision=code)
             with torch.no_grad():
-                step32()
+                step_other()
                 torch.cuda.synchronize()
                 lib.idealnerf_profile_begin()
                 t1 = time.perf_counter()
                 for _ in range(2):
-                    step32()
+                    o_out = step_other()
                 torch.cuda.synchronize()
-                d32 = time.perf_counter() - t1
+                d_o = time.perf_counter() - t1
             lib.idealnerf_profile_end(C.byref(k_ms), C.byref(k_n), C.byref(k_pts))
-            a32 = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12
-            res["f32_mode"] = {"value": H * W * (S + S + Ni) * 2 / d32, "unit": "ray-samples/s", "ms_per_step": d32 / 2 * 1e3,
-                               "roofline": {"bound": "mfma", "achieved": a32, "peak": PEAK_F32_MFMA_TFLOPS,
-                                            "unit": "TFLOP/s", "frac": a32 / PEAK_F32_MFMA_TFLOPS},
-                               "note": "IDN_PREC_F32: v_mfma_f32_32x32x2_f32, exact fp32 fma chains"}
+            a_o = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12
+            peak_o = PEAK_F32_MFMA_TFLOPS if other == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+            diff = (o_out["rgb_map"].reshape(-1, 3).double() - tile.reshape(-1, 3).double())
+            res[other + "_mode"] = {
+                "value": H * W * (S + S + Ni) * 2 / d_o, "unit": "ray-samples/s", "ms_per_step": d_o / 2 * 1e3,
+                "roofline": {"bound": "mfma", "achieved": a_o, "peak": peak_o, "unit": "TFLOP/s", "frac": a_o / peak_o},
+                "rgb_vs_headline_frame": {"max_abs": float(diff.abs().max()), "psnr_db": float(-10.0 * torch.log10((diff ** 2).mean().clamp_min(1e-30)))},
+                "note": ("IDN_PREC_BF16X3: 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; priced against bf16 peak / 3"
+                         if other == "bf16x3" else "IDN_PREC_F32: v_mfma_f32_32x32x2_f32, exact fp32 fma chains")}
             coarse.precision = fine.precision = args.precision
         if world == 1 and not args.no_cpu_baseline:
             pc = {k: v.detach().cpu() for k, v in coarse.state_dict().items()}

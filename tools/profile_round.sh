@@ -3,7 +3,7 @@
 # its own pass, --pmc never combined with trace domains).  Results under gpurun_out/prof/.
 set -e
 export TMPDIR=/tmp
-P=${1:-bf16x3}
+P=${1:-f32}
 O=gpurun_out/prof_$P
 rm -rf $O; mkdir -p $O
 B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-mode --precision $P"
