@@ -299,7 +299,9 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         auto layer = [&](auto F0c, auto NTc, auto KGc, auto DEFERc, auto& out, f32x16* deferred, auto&& bget,
                          const float* bias_l, int save_idx) {
             constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KG = decltype(KGc)::value;
-            constexpr bool LAST = (F0 + NT * KG == kUsedFrags);
+            // no read-ahead past the end of the pass, nor past views_linears.0's four hidden tiles (the sigma tile's
+            // fragments that follow them are walked, not read)
+            constexpr bool LAST = (F0 + NT * KG == kUsedFrags) || F0 == layer_f0(8);
             constexpr bool DEFER = decltype(DEFERc)::value != 0;
             DIAG_BEGIN(dg);
             if constexpr (SAVE) load_bias<NT>(out, bias_l);
@@ -339,16 +341,44 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         // ---- pts_linears.6, .7
         layer(ic<layer_f0(6)>{}, ic<8>{}, ic<32>{}, ic<D>{}, A, &B[7], tiles_get(B), bias_h + bias_off(6), kActA1 + 6);
         layer(ic<layer_f0(7)>{}, ic<8>{}, ic<32>{}, ic<D>{}, B, &A[7], tiles_get(A), bias_h + bias_off(7), kActA1 + 7);
-        // ---- views_linears.0 (+ alpha_linear as channel 128) : [256 | dirPE(32)] -> 160
-        //      tiles 0..3 are hidden units (ReLU'd while the next tile accumulates), tile 4 row 0 is sigma
-        layer(ic<layer_f0(8)>{}, ic<5>{}, ic<36>{}, ic<D>{}, V, &B[7],
+        // ---- views_linears.0 : [256 | dirPE(32)] -> 128.  The stream still carries alpha_linear as a fifth tile
+        //      (the bf16 kernels use it); here its 36 fragments are walked without being read, and sigma is a
+        //      256-term dot product on the vector unit: 128 FMAs per lane against 144 MFMAs (one row of 32 used).
+        f32x16(&V4a)[4] = reinterpret_cast<f32x16(&)[4]>(V);
+        layer(ic<layer_f0(8)>{}, ic<4>{}, ic<36>{}, ic<D>{}, V4a, &B[7],
               [&](auto G, auto J) {
                   constexpr int g = decltype(G)::value, j = decltype(J)::value;
                   if constexpr (g < 32) return B[g >> 2][(g & 3) * 4 + j];
                   else return pd[g - 32][j];
               },
               bias_h + bias_off(8), -1);
-        const float sigma = V[4][0];  // channel 128 = tile 4, register 0, lane half 0
+        if constexpr (!SAVE) relu_regs<0, 16>(V[3]);   // the sigma tile used to give the fourth tile's ReLU its shadow
+        {
+            constexpr int f_from = layer_f0(8) + 4 * 36, f_to = layer_f0(9);
+            static_assert(f_from / kSliceFrags == (f_to - 1) / kSliceFrags && f_to % kSliceFrags != 0, "the walk stays inside one open slice");
+            static_for<(f_to - f_from) / 2>([&](auto I) { ws.template step_piece<f_from + 2 * decltype(I)::value>(); });
+            fr.pref0 = fr.template issue<f_to>();
+            fr.pref1 = fr.template issue<f_to + 1>();
+        }
+        float sigma;
+        {
+            // B holds h7 (post-ReLU; its last tile was finished inside the layer above): this lane has the
+            // channels 32t + 8q + 4h + i, the weights sit in LDS in the same order as a bias row
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            static_for<8>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                static_for<4>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(bias_h + kAlphaOff + 32 * t + 8 * q);
+                    s0 = fmaf(w.x, B[t][4 * q + 0], s0);
+                    s1 = fmaf(w.y, B[t][4 * q + 1], s1);
+                    s2 = fmaf(w.z, B[t][4 * q + 2], s2);
+                    s3 = fmaf(w.w, B[t][4 * q + 3], s3);
+                });
+            });
+            const float part = (s0 + s1) + (s2 + s3);
+            sigma = bias_s[bias_off(8) + kSigmaChannel] + (part + __shfl_xor(part, 32, 64));   // both lane halves
+        }
         if constexpr (SAVE) {
             DIAG_BEGIN(dg);
             f32x16(&V4)[4] = reinterpret_cast<f32x16(&)[4]>(V);

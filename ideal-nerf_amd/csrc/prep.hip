@@ -194,6 +194,10 @@ __device__ __forceinline__ float cond_at(const FoldDesc& d, int c) {
 __global__ void fold_kernel(FoldDesc d, float* out) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= kBiasFloats) return;
+    if (o >= kAlphaOff) {   // alpha_linear's weight row, for the fp32 kernel's vector-unit sigma
+        out[o] = d.p.alpha_w[o - kAlphaOff];
+        return;
+    }
     int l = o / 256, n = o % 256;
     if (o >= bias_off(8)) {
         const int r = o - bias_off(8);
