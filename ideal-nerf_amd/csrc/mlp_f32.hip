@@ -34,12 +34,14 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 // would retire that read, the compiler would treat its destination registers as dead and
 // reuse them (e.g. as a global address) while the LDS data is still on its way
 // (tools/audit_asm_loads.py checks the ISA for this).
-template <int F0, int NT, int KG, bool LAST = false, class BGet, class Side>
-__device__ __forceinline__ void run_layer(f32x16 (&out)[NT], BGet&& bget, WStream& ws, FragReader& fr, Side&& side) {
+template <int F0, int NT, int KG, bool LAST = false, class BGet, class Side, class Hook = NoHook>
+__device__ __forceinline__ void run_layer(f32x16 (&out)[NT], BGet&& bget, WStream& ws, FragReader& fr, Side&& side,
+                                          Hook&& after_open = NoHook{}) {
     constexpr int STEPS = KG / 2, NP = NT * STEPS;
     static_assert(KG % 2 == 0 && F0 % 2 == 0, "fragments are consumed in pairs");
     if constexpr (F0 % kSliceFrags == 0) {
         ws.open_slice();
+        after_open();   // global loads issued here have a whole slice to land before the next barrier's vmcnt(0)
         fr.pref0 = fr.template issue<F0>();
         fr.pref1 = fr.template issue<F0 + 1>();
     }
@@ -205,6 +207,9 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
     const float* bias_h = bias_s + 4 * h;
     const long ntiles = (a.n_points + 127) >> 7;
 
+    PointIn cur, nxt;   // raw inputs of this lane's point, loaded one pass ahead (mlp_common.h)
+    load_point<MODE>(a, blockIdx.x, wave, m, cur);
+    nxt = cur;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         DIAG_ONLY(const unsigned long long t_tile = clock64(); dg.begin();)
         const long P = tile * 128 + wave * 32 + m;
@@ -230,27 +235,8 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
                 });
             });
         } else {
-            const long ray = Pc / a.S;
             float p[3], v[3];
-            if constexpr (MODE == kModeRays) {
-                const float* rr = a.rays + ray * IDN_RAY_FLOATS;
-                const float zz = a.z[Pc];
-                // pts = rays_o + rays_d * z, product and sum rounded separately
-                // (audio_exp_nerf.py:332; this file is built with -ffp-contract=off)
-                p[0] = rr[0] + rr[3] * zz;
-                p[1] = rr[1] + rr[4] * zz;
-                p[2] = rr[2] + rr[5] * zz;
-                v[0] = rr[8];
-                v[1] = rr[9];
-                v[2] = rr[10];
-            } else {
-                p[0] = a.pts[Pc * 3 + 0];
-                p[1] = a.pts[Pc * 3 + 1];
-                p[2] = a.pts[Pc * 3 + 2];
-                v[0] = a.dirs[ray * 3 + 0];
-                v[1] = a.dirs[ray * 3 + 1];
-                v[2] = a.dirs[ray * 3 + 2];
-            }
+            point_of<MODE>(cur, p, v);
             PeAxes axp, axd;
             axp.init(p, h);
             axd.init(v, h);
@@ -303,6 +289,12 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
             // fragments that follow them are walked, not read)
             constexpr bool LAST = (F0 + NT * KG == kUsedFrags) || F0 == layer_f0(8);
             constexpr bool DEFER = decltype(DEFERc)::value != 0;
+            static_assert(layer_f0(5) % kSliceFrags == 0 && layer_f0(6) % kSliceFrags == 0, "input prefetch hooks sit on slice boundaries");
+            // the next tile's point inputs: loaded after pts_linears.5's first slice opens, touched one layer later
+            auto hook = [&]() {
+                if constexpr (MODE != kModeX && F0 == layer_f0(5)) load_point<MODE>(a, tile + gridDim.x, wave, m, nxt);
+                if constexpr (MODE != kModeX && F0 == layer_f0(6)) touch_point(nxt);
+            };
             DIAG_BEGIN(dg);
             if constexpr (SAVE) load_bias<NT>(out, bias_l);
             else bias_tile(out[0], bias_l);
@@ -311,13 +303,13 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
                 if (save_idx >= 0) {  // hidden layer: ReLU + record, in the MFMA shadow
                     const SaveSide<NT, KG / 2, 32 * NT> side{&out[0], rows_rsrc(a.acts + (long)act_off(save_idx) * a.p_pad + p0 * (32 * NT), 32 * NT),
                                                              (uint32_t)((h * (32 * NT) + m) * 4), stage, rb, raddr, m, h};
-                    run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, side);
+                    run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, side, hook);
                     side.finish();
                 } else {
-                    run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, NoSide{});
+                    run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, NoSide{}, hook);
                 }
             } else {
-                run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, LayerSide<NT, KG / 2, DEFER>{&out[0], deferred, bias_l});
+                run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, LayerSide<NT, KG / 2, DEFER>{&out[0], deferred, bias_l}, hook);
             }
         };
         constexpr bool D = !SAVE;  // deferred last-tile ReLU only exists on the inference path
@@ -409,6 +401,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         }
         DIAG_END(dg, kDgStore);
         DIAG_ONLY(dg.acc[kDgTotal] += clock64() - t_tile;)
+        cur = nxt;
     }
 #ifdef IDN_DIAG
     if (lane == 0)
