@@ -81,9 +81,11 @@ constexpr int bias_off(int l) {
 // ... followed by a copy of alpha_linear's weight row (256 floats): the fp32 kernel takes sigma as a
 // 256-term dot product on the vector unit instead of a fifth 32-row MFMA tile of views_linears.0
 // of which one row is used (1.6 % of the pass's MFMAs).
+// and of rgb_linear's three weight rows (3 x 128): the same for the colour head (3 rows of 32 used).
 constexpr int kAlphaOff = bias_off(kNumLayers);    // 2496
-constexpr int kBiasFloats = kAlphaOff + 256;       // 2752
-static_assert(kBiasFloats == 2752, "bias table changed");
+constexpr int kRgbOff = kAlphaOff + 256;           // 2752
+constexpr int kBiasFloats = kRgbOff + 3 * 128;     // 3136
+static_assert(kBiasFloats == 3136, "bias table changed");
 
 // views0 carries sigma as channel 128 (tile 4, row 0): alpha_linear rides in the same
 // pass over the trunk output instead of a separate N=1 layer.

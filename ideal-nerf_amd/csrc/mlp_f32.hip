@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
             constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KG = decltype(KGc)::value;
             // no read-ahead past the end of the pass, nor past views_linears.0's four hidden tiles (the sigma tile's
             // fragments that follow them are walked, not read)
-            constexpr bool LAST = (F0 + NT * KG == kUsedFrags) || F0 == layer_f0(8);
+            constexpr bool LAST = (F0 + NT * KG == kUsedFrags) || F0 == layer_f0(8) || F0 == layer_f0(10);
             constexpr bool DEFER = decltype(DEFERc)::value != 0;
             static_assert(layer_f0(5) % kSliceFrags == 0 && layer_f0(6) % kSliceFrags == 0, "input prefetch hooks sit on slice boundaries");
             // the next tile's point inputs: loaded after pts_linears.5's first slice opens, touched one layer later
@@ -385,17 +385,43 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         f32x16(&V4b)[4] = reinterpret_cast<f32x16(&)[4]>(V);
         layer(ic<layer_f0(9)>{}, ic<4>{}, ic<16>{}, ic<0>{}, A4, nullptr, tiles_get(V), bias_h + bias_off(9), kActV1 + 1);
         layer(ic<layer_f0(10)>{}, ic<4>{}, ic<16>{}, ic<D>{}, V4b, &A[3], tiles_get(A), bias_h + bias_off(10), kActV1 + 2);
-        // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile)
-        f32x16 rgb[1];
-        layer(ic<layer_f0(11)>{}, ic<1>{}, ic<16>{}, ic<D>{}, rgb, &V[3], tiles_get(V), bias_h + bias_off(11), -1);
-        finish_pass<kUsedFrags>(ws);
+        // ---- rgb_linear : 128 -> 3.  Like sigma: three 128-term dot products on the vector unit instead of a
+        //      32-row MFMA tile of which three rows are used; its 16 fragments are walked with the padding.
+        //      One tile at a time, fenced: left alone the scheduler hoists all 48 weight reads (192 registers).
+        if constexpr (!SAVE) relu_regs<0, 16>(V[3]);   // owed by views_linears.2 (its last tile's ReLU was deferred)
+        finish_pass<layer_f0(11)>(ws);
+        float rgb[3] = {bias_s[bias_off(11) + 0], bias_s[bias_off(11) + 1], bias_s[bias_off(11) + 2]};
+        {
+            float part[3] = {0.f, 0.f, 0.f};
+            static_for<4>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                f32x16 vt = V[t];
+                asm volatile("" : "+v"(vt));   // the tile's 16 values in VGPRs before its weights are read
+                static_for<3>([&](auto Cc) {
+                    constexpr int c = decltype(Cc)::value;
+                    static_for<4>([&](auto Q) {
+                        constexpr int q = decltype(Q)::value;
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(bias_h + kRgbOff + 128 * c + 32 * t + 8 * q);
+                        part[c] = fmaf(w.x, vt[4 * q + 0], part[c]);
+                        part[c] = fmaf(w.y, vt[4 * q + 1], part[c]);
+                        part[c] = fmaf(w.z, vt[4 * q + 2], part[c]);
+                        part[c] = fmaf(w.w, vt[4 * q + 3], part[c]);
+                    });
+                });
+                asm volatile("" : "+v"(part[0]), "+v"(part[1]), "+v"(part[2])::"memory");
+            });
+            static_for<3>([&](auto Cc) {
+                constexpr int c = decltype(Cc)::value;
+                rgb[c] += part[c] + __shfl_xor(part[c], 32, 64);
+            });
+        }
 
         DIAG_BEGIN(dg);
         if (valid && h == 0) {
             f32x4 o;
-            o.x = rgb[0][0];
-            o.y = rgb[0][1];
-            o.z = rgb[0][2];
+            o.x = rgb[0];
+            o.y = rgb[1];
+            o.z = rgb[2];
             o.w = sigma;
             *reinterpret_cast<f32x4*>(a.raw + P * 4) = o;
         }

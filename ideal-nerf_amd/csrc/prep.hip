@@ -194,8 +194,8 @@ __device__ __forceinline__ float cond_at(const FoldDesc& d, int c) {
 __global__ void fold_kernel(FoldDesc d, float* out) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= kBiasFloats) return;
-    if (o >= kAlphaOff) {   // alpha_linear's weight row, for the fp32 kernel's vector-unit sigma
-        out[o] = d.p.alpha_w[o - kAlphaOff];
+    if (o >= kAlphaOff) {   // alpha_linear's / rgb_linear's weight rows, for the fp32 kernel's vector-unit heads
+        out[o] = o < kRgbOff ? d.p.alpha_w[o - kAlphaOff] : d.p.rgb_w[o - kRgbOff];
         return;
     }
     int l = o / 256, n = o % 256;
