@@ -41,7 +41,7 @@ class RenderArgs(C.Structure):
                                   "rgb0", "disp0", "acc0", "z_std", "last_weight0", "rgb_fg0",
                                   "tap_z_coarse", "tap_raw_coarse", "tap_weights_coarse", "tap_cdf", "tap_inds",
                                   "tap_z_samples", "tap_z_fine", "tap_raw_fine", "tap_weights_fine")] + \
-               [("workspace", fp), ("workspace_bytes", C.c_size_t)]
+               [("workspace", fp), ("workspace_bytes", C.c_size_t), ("precision_fine_plus1", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/idealnerf.h one to one

@@ -121,10 +121,13 @@ class Network(nn.Module):
         with torch.no_grad():
             fc = coarse.folded_bias(aud_para, expr, latent_code)
             ff = fine.folded_bias(aud_para, expr, latent_code) if Ni > 0 else None
+            # each network renders in its own arithmetic: coarse "f32" + fine "bf16x3" is the mixed mode (the
+            # coarse output drives the importance sampling, which amplifies arithmetic noise; nothing is
+            # sampled after the fine pass)
             out = ops.render_rays_fwd(rays, bc_rgb, coarse.packed_weights(), fc,
-                                      fine.packed_weights(coarse.precision) if Ni > 0 else None, ff,
+                                      fine.packed_weights() if Ni > 0 else None, ff,
                                       linspace01(S, dev), u, Ni, t_rand=t_rand, with_fg=with_fg, taps=taps or retraw,
-                                      precision=coarse.prec_code)
+                                      precision=coarse.prec_code, precision_fine=fine.prec_code if Ni > 0 else None)
         ret = {'rgb_map': out['rgb_map'], 'disp_map': out['disp_map'], 'acc_map': out['acc_map']}
         if with_fg:
             ret['rgb_map_fg'] = out['rgb_fg']

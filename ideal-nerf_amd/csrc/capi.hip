@@ -298,6 +298,8 @@ size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_imp
 int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
     if (!a) return fail(IDN_EINVAL, "args is NULL");
     if (int e = check_precision(a->precision)) return e;
+    const int prec_fine = a->precision_fine_plus1 ? a->precision_fine_plus1 - 1 : a->precision;
+    if (int e = check_precision(prec_fine)) return e;
     const int64_t n = a->n_rays;
     const int S = a->n_samples, Ni = a->n_importance, Sf = S + Ni;
     if (n < 0 || S < 2 || Ni < 0) return fail(IDN_EINVAL, "bad sizes n=%lld S=%d Ni=%d", (long long)n, S, Ni);
@@ -345,7 +347,7 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
                                       off(a->tap_z_samples, r0 * Ni), off(a->tap_inds, r0 * Ni),
                                       off(a->tap_cdf, r0 * (S - 1)), w.z_f, off(a->z_std, r0), st))
             return e;
-        if (int e = launch_mlp(a->precision, a->packed_fine, a->folded_fine, nullptr, rays, w.z_f, nullptr, nullptr, c * Sf, Sf, w.raw_f, st)) return e;
+        if (int e = launch_mlp(prec_fine, a->packed_fine, a->folded_fine, nullptr, rays, w.z_f, nullptr, nullptr, c * Sf, Sf, w.raw_f, st)) return e;
         idn_composite_out fo = {};
         fo.rgb_map = off(a->rgb_map, r0 * 3);
         fo.disp_map = off(a->disp_map, r0);

@@ -194,8 +194,9 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, n_importance,
-                    t_rand=None, with_fg=False, taps=False, precision=IDN_PREC_F32) -> Dict[str, torch.Tensor]:
-    """Network.render_rays forward (audio_exp_nerf.py:297-371) as one C call."""
+                    t_rand=None, with_fg=False, taps=False, precision=IDN_PREC_F32, precision_fine=None) -> Dict[str, torch.Tensor]:
+    """Network.render_rays forward (audio_exp_nerf.py:297-371) as one C call.  `precision_fine` (default: the
+    same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it."""
     lib = _lib.load()
     n, S, Ni = rays.shape[0], t_vals.shape[0], int(n_importance)
     dev = rays.device
@@ -218,6 +219,7 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
     a = _lib.RenderArgs()
     a.rays, a.bc_rgb, a.n_rays = _ptr(rays, "rays"), _ptr(bc_rgb, "bc_rgb"), n
     a.n_samples, a.n_importance, a.precision = S, Ni, precision
+    a.precision_fine_plus1 = 0 if precision_fine is None else int(precision_fine) + 1
     a.packed_coarse, a.folded_coarse = _ptr(packed_c), _ptr(folded_c)
     a.packed_fine, a.folded_fine = _ptr(packed_f), _ptr(folded_f)
     a.t_vals, a.t_rand = _ptr(t_vals, "t_vals"), _ptr(t_rand, "t_rand")

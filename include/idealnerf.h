@@ -203,6 +203,12 @@ typedef struct idn_render_args {
     float* tap_weights_fine; /* [n,S+Ni]*/
     void* workspace;       /* idealnerf_render_workspace_bytes() bytes */
     size_t workspace_bytes;
+    /* Arithmetic of the FINE network's launches: 0 = same as `precision`, else IDN_PREC_* + 1.
+     * "mixed" rendering = precision IDN_PREC_F32 with precision_fine_plus1 = IDN_PREC_BF16X3 + 1: the
+     * coarse pass, whose output drives the importance sampling (which amplifies arithmetic noise), stays
+     * exact; the fine pass (3/4 of the samples, nothing sampled after it) runs at the bf16 matrix rate.
+     * packed_fine must have been packed for that arithmetic. */
+    int precision_fine_plus1;
 } idn_render_args;
 
 size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);

@@ -47,17 +47,17 @@ def test_ctypes_structs_match_c_layout(idn, tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "idealnerf.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(idn_facenerf_params), '
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(idn_facenerf_params), '
         'sizeof(idn_composite_out), sizeof(idn_render_args), offsetof(idn_facenerf_params, dim_aud), '
         'offsetof(idn_render_args, t_vals), offsetof(idn_render_args, tap_inds), '
-        'offsetof(idn_render_args, workspace_bytes));return 0;}\n')
+        'offsetof(idn_render_args, workspace_bytes), offsetof(idn_render_args, precision_fine_plus1));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     L = idn._lib
     want = [C.sizeof(L.FaceNerfParams), C.sizeof(L.CompositeOut), C.sizeof(L.RenderArgs),
             L.FaceNerfParams.dim_aud.offset, L.RenderArgs.t_vals.offset, L.RenderArgs.tap_inds.offset,
-            L.RenderArgs.workspace_bytes.offset]
+            L.RenderArgs.workspace_bytes.offset, L.RenderArgs.precision_fine_plus1.offset]
     assert got == want
 
 
