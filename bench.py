@@ -128,10 +128,14 @@ def bench_torso(args):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", int(os.environ.get("IDN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("IDN_DIST_BACKEND", "nccl")   # gloo only to rehearse on a one-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     H = W = args.size
     prec = args.precision if args.precision_given else "bf16"
     syn = synthetic.frame(H, W, seed=rank)   # every rank renders a different frame of the clip
