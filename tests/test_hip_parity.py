@@ -1108,3 +1108,34 @@ def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golde
     assert rel_err(out["rgb_map"], g["rgb"].reshape(-1, 3)) < RGB_TOL and rel_err(out["rgb0"], g["rgb0"].reshape(-1, 3)) < 1e-5
     flips = (out["tap_inds"].cpu().numpy() != g["tap_inds"].astype(np.int64)).mean()
     assert flips < 1e-3   # the fp32 kernel's own flip rate, not bf16x3's
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_scenes_fp32_and_mixed_vs_oracle(idn, dev, seed):
+    """Fresh weights, pose, conditioning and a random ray subset per seed: the fp32 and the mixed mode
+    against the CPU oracle (which is pinned to the reference), every output finite."""
+    dims = oracle.facenerf_dims()
+    rs = np.random.RandomState(seed)
+    pc = scale_sigma(oracle.xavier_facenerf_params(100 + seed, dims), float(rs.uniform(30, 300)), float(rs.uniform(-0.2, 0.4)))
+    pf = scale_sigma(oracle.xavier_facenerf_params(200 + seed, dims), float(rs.uniform(30, 300)), float(rs.uniform(-0.2, 0.4)))
+    syn = oracle.synthetic_frame(32, 32, seed=seed, dims=dims)
+    rays = idn.ops.frame_rays(syn["c2w"], 32, 32, syn["focal"], NEAR, FAR, device=dev)
+    sel = torch.from_numpy(rs.choice(1024, 160, replace=False))
+    r = rays[sel.to(dev)].contiguous()
+    bc = syn["bc"].reshape(-1, 3)[sel].contiguous()
+    cond = (syn["aud"], syn["expr"], syn["latent"])
+    with torch.no_grad():
+        ref = oracle.render_rays(r.cpu(), bc, pc, pf, *cond, n_samples=64, n_importance=128, dims=dims)
+    t, u = torch.linspace(0.0, 1.0, 64).to(dev), torch.linspace(0.0, 1.0, 128).to(dev)
+    for mode, (prec_c, prec_f) in (("f32", (0, 0)), ("mixed", (0, 1))):
+        packs = []
+        for p, prec in ((pc, prec_c), (pf, prec_f)):
+            sd = {k: v.to(dev).contiguous() for k, v in p.items()}
+            ps = idn.ops.params_struct(sd, 64, 76, 32)
+            packs.append((idn.ops.pack_weights(ps, dev, prec), idn.ops.fold_conditioning(ps, *(c.to(dev) for c in cond), dev), sd))
+        out = idn.ops.render_rays_fwd(r, bc.to(dev), packs[0][0], packs[0][1], packs[1][0], packs[1][1], t, u, 128,
+                                      precision=prec_c, precision_fine=prec_f)
+        for k in ("rgb_map", "rgb0", "disp_map", "acc_map", "last_weight", "z_std"):
+            assert bool(torch.isfinite(out[k]).all()), (mode, k)
+        assert rel_err(out["rgb_map"], ref["rgb_map"]) < RGB_TOL, mode
+        assert rel_err(out["rgb0"], ref["rgb0"]) < RGB_TOL, mode
