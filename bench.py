@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--no-f32-mode", "--no-side-mode", dest="no_f32_mode", action="store_true",
                     help="skip the side measurement of the other arithmetic mode (profiling runs)")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--soak", action="store_true",
+                    help="compare every timed frame with the first one bit for bit (the path is deterministic: a mismatch is "
+                         "a race); reported as `soak_mismatched_frames`")
     ap.add_argument("--precision", choices=["f32", "mixed", "bf16x3", "bf16"], default=os.environ.get("IDN_PRECISION", "f32"),
                     help="arithmetic of the MLP contraction.  f32 (default, the headline line): exact fp32 MFMA chains, "
                          "RGB within 1e-6..1e-5 of the reference.  bf16x3: three bf16 MFMAs per product, 3.4x faster, "
@@ -276,9 +279,15 @@ def main():
             step()
         fence()
         lib.idealnerf_profile_begin()
+        first, mismatched = None, torch.zeros((), dtype=torch.int64, device=dev)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             frame, tile = step()
+            if args.soak:
+                if first is None:
+                    first = tile.clone()
+                else:
+                    mismatched += (tile != first).any().to(torch.int64)
         fence()
         dt = time.perf_counter() - t0
     import ctypes as C
@@ -319,6 +328,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)", "mixed": "f32 coarse network + bf16x3 fine network"}[args.precision], "data": "synthetic",
             "per_gpu": value / world, "rays_per_s": value / (S + S + Ni),
+            **({"soak_mismatched_frames": int(mismatched.item())} if args.soak else {}),
             "config": {"workload": f"BASELINE configs[1]: May HeadNeRF {H}x{W} full-frame render, N_sample=64 "
                                    "N_importance=128, dim_aud=64 dim_expr=76 latent=32, perturb=0",
                        "rays_per_step": H * W, "samples_per_ray": S + S + Ni,
