@@ -78,6 +78,7 @@ def bench_train(args):
     import numpy as np
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
+    torch.manual_seed(0)   # perturb=1 draws the stratified offsets from torch's generator: same run, same loss
     H = W = 450
     syn = synthetic.frame(H, W, seed=0)
     cfg = RenderConfig(perturb=1.0, chunk=8192, near=syn["near"], far=syn["far"])
