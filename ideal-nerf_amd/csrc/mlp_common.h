@@ -83,15 +83,19 @@ struct WStreamT {
     uint32_t soff;      // byte offset of the slice currently being fetched (wave-uniform)
     int next_slice;
     int num_slices;     // slices in this stream (kNumSlices, or kPlainNumSlices for the plain-bf16 stream)
-    char* ring_wave;    // ring + wave * 1 KiB (wave-uniform LDS destination base)
+    char* ring_wave;    // ring + this wave's block of a slice (wave-uniform LDS destination base)
 
     __device__ __forceinline__ void init(const float* stream, int slices, char* ring, int tid, int wave) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, slices * kSliceBytes, 0x00020000);  // raw, untyped
-        voff = tid * 16;
+        // wave w fetches the kPieces consecutive fragments w * kPieces .. of every slice: four consecutive
+        // pieces then differ only in the instruction's immediate offset (1 KiB steps, applied to the global
+        // and the LDS address alike), so a slot needs kPieces / 4 M0 / scalar-offset values instead of
+        // kPieces -- the per-site constants the compiler keeps in SGPRs (and spills through VALU lanes)
+        voff = (tid & 63) * 16 + wave * (kPieces * kFragBytes);
         soff = 0;
         next_slice = 0;
         num_slices = slices;
-        ring_wave = ring + wave * kFragBytes;
+        ring_wave = ring + wave * (kPieces * kFragBytes);
         static_for<kAhead>([&](auto S_) { issue_rest<decltype(S_)::value, 0>(); });  // slices 0 .. kAhead-1
     }
     __device__ __forceinline__ void advance() {
@@ -103,8 +107,8 @@ struct WStreamT {
     }
     template <int SLOT, int J>
     __device__ __forceinline__ void issue_piece() {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(ring_wave + SLOT * kSliceBytes + J * kPieceBytes), 16, voff,
-                                                 soff + J * kPieceBytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(ring_wave + SLOT * kSliceBytes + (J / 4) * (4 * kFragBytes)), 16, voff,
+                                                 soff + (J / 4) * (4 * kFragBytes), (J % 4) * kFragBytes, 0);
         if constexpr (J == kPieces - 1) advance();
     }
     template <int SLOT, int J0>
