@@ -144,7 +144,7 @@ def bench_torso(args):
     net = Network(H, W, syn["focal"], syn["near"], syn["far"], 32768, None, 64, 128, args=cfg, dim_expr_head=76).to(dev).eval()
     for i, m in enumerate((net.face_nerf_coarse, net.face_nerf_fine, net.torso_coarse_nerf, net.torso_fine_nerf)):
         synthetic.xavier_state_dict(m, 2 + i, 300.0 if i < 2 else 4.0, 0.3 if i < 2 else -0.2)
-        m.precision = prec
+    idealnerf_amd.set_render_precision(net, prec)   # "mixed" = fp32 coarse + bf16x3 fine network of each pair
     g = lambda t: t.to(dev)
     aud, expr, latent, bc = g(syn["aud"]), g(syn["expr"]), g(syn["latent"]), g(syn["bc"])
     pose = g(torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0))
