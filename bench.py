@@ -202,7 +202,7 @@ def main():
     ap.add_argument("--soak", action="store_true",
                     help="compare every timed frame with the first one bit for bit (the path is deterministic: a mismatch is "
                          "a race); reported as `soak_mismatched_frames`")
-    ap.add_argument("--precision", choices=["f32", "mixed", "bf16x3", "bf16"], default=os.environ.get("IDN_PRECISION", "f32"),
+    ap.add_argument("--precision", choices=["f32", "mixed", "fp16x3", "bf16x3", "bf16"], default=os.environ.get("IDN_PRECISION", "f32"),
                     help="arithmetic of the MLP contraction.  f32 (default, the headline line): exact fp32 MFMA chains, "
                          "RGB within 1e-6..1e-5 of the reference.  bf16x3: three bf16 MFMAs per product, 3.4x faster, "
                          "within the 1e-4 RGB budget on the reference's golden frame and this scene, but sharp scenes "
@@ -318,16 +318,18 @@ def main():
         # mixed = two kernels with two peaks (1/4 of the samples on the fp32 path, 3/4 on bf16x3): the blended
         # peak is total FLOP / (coarse FLOP / fp32 peak + fine FLOP / (bf16 peak / 3)), so frac = ideal time / actual
         mixed_peak = 1.0 / (0.25 / PEAK_F32_MFMA_TFLOPS + 0.75 / (PEAK_BF16_MFMA_TFLOPS / 3.0))
-        peaks = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16": PEAK_BF16_MFMA_TFLOPS, "mixed": mixed_peak}
+        peaks = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3.0,
+                 "bf16": PEAK_BF16_MFMA_TFLOPS, "mixed": mixed_peak}   # the dense fp16 and bf16 MFMA peaks are equal on gfx950
         peak = peaks[args.precision]
         kname = {"f32": "idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)",
                  "bf16x3": "idn::mlp_bf16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 bf16 MFMAs per product)",
                  "bf16": "idn::mlp_bf16_kernel<kModeRays> (fused PE + FaceNeRF MLP, plain bf16 MFMA)",
+                 "fp16x3": "idn::mlp_fp16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 fp16 MFMAs per product)",
                  "mixed": "idn::mlp_f32_kernel (coarse network) + idn::mlp_bf16x3_kernel (fine network); blended peak"}[args.precision]
         res = {
             "metric": "ray-samples/sec (64+128 pts, 512x512), whole job", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)", "mixed": "f32 coarse network + bf16x3 fine network"}[args.precision], "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)", "mixed": "f32 coarse network + bf16x3 fine network", "fp16x3": "fp16x3 (fp32 in/out, fp32 accumulate)"}[args.precision], "data": "synthetic",
             "per_gpu": value / world, "rays_per_s": value / (S + S + Ni),
             **({"soak_mismatched_frames": int(mismatched.item())} if args.soak else {}),
             "config": {"workload": f"BASELINE configs[1]: May HeadNeRF {H}x{W} full-frame render, N_sample=64 "
@@ -351,7 +353,9 @@ def main():
                      "bf16x3": "IDN_PREC_BF16X3: 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; priced against bf16 peak / 3",
                      "mixed": "coarse network (drives the importance sampling) in exact fp32, fine network (3/4 of the samples) in "
                               "bf16x3; priced against the blended peak of the two kernels"}
-            for other in (["mixed", "bf16x3"] if args.precision == "f32" else ["f32"]):
+            notes["fp16x3"] = ("IDN_PREC_FP16X3: 3 x v_mfma_f32_32x32x16_f16 per product (11+11 significand bits per operand), "
+                               "fp32 accumulate; priced against the fp16 (= bf16) peak / 3")
+            for other in (["fp16x3", "mixed", "bf16x3"] if args.precision == "f32" else ["f32"]):
                 set_mode(other)
                 pko_c, pko_f = coarse.packed_weights(), fine.packed_weights()
                 code_c, code_f = coarse.prec_code, fine.prec_code

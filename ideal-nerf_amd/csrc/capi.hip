@@ -16,8 +16,9 @@ int fail(int code, const char* fmt, ...) {
 }
 
 static int check_precision(int precision) {
-    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3 || precision == IDN_PREC_BF16) return IDN_OK;
-    return fail(IDN_EUNSUPPORTED, "precision %d is unknown (IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16)", precision);
+    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3 || precision == IDN_PREC_BF16 || precision == IDN_PREC_FP16X3)
+        return IDN_OK;
+    return fail(IDN_EUNSUPPORTED, "precision %d is unknown (IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16, IDN_PREC_FP16X3)", precision);
 }
 static int check_precision_f32(int precision) {
     if (precision == IDN_PREC_F32) return IDN_OK;
@@ -33,6 +34,8 @@ int launch_mlp(int precision, const float* packed, const float* folded, const fl
         return launch_mlp_bf16x3(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
     if (precision == IDN_PREC_BF16)
         return launch_mlp_bf16(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
+    if (precision == IDN_PREC_FP16X3)
+        return launch_mlp_fp16x3(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
     return launch_mlp_f32(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
 }
 
@@ -83,7 +86,7 @@ const char* idealnerf_last_error(void) { return g_err; }
 
 size_t idealnerf_packed_weight_floats(int precision) {
     // 4 bytes per weight (fp32, or bf16 hi + bf16 lo); 2 for the plain-bf16 stream
-    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3) return (size_t)kStreamFrags * kFragFloats;
+    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3 || precision == IDN_PREC_FP16X3) return (size_t)kStreamFrags * kFragFloats;
     if (precision == IDN_PREC_BF16) return (size_t)kPlainStreamFrags * kFragFloats;
     return 0;
 }
@@ -94,6 +97,7 @@ int idealnerf_pack_weights(const idn_facenerf_params* p, int precision, float* p
     if (int e = check_precision(precision)) return e;
     if (!packed) return fail(IDN_EINVAL, "packed is NULL");
     if (precision == IDN_PREC_BF16X3) return launch_pack_bf16x3(*p, packed, (hipStream_t)stream);
+    if (precision == IDN_PREC_FP16X3) return launch_pack_bf16x3(*p, packed, (hipStream_t)stream, 1);
     if (precision == IDN_PREC_BF16) return launch_pack_bf16(*p, packed, (hipStream_t)stream);
     return launch_pack_f32(*p, packed, (hipStream_t)stream);
 }

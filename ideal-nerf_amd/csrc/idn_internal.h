@@ -161,11 +161,13 @@ struct ProfScope {
 // launchers (one per .hip file)
 // ---------------------------------------------------------------------------
 int launch_pack_f32(const idn_facenerf_params& p, float* packed, hipStream_t s);
-int launch_pack_bf16x3(const idn_facenerf_params& p, float* packed, hipStream_t s);
+int launch_pack_bf16x3(const idn_facenerf_params& p, float* packed, hipStream_t s, int fmt = 0);  // fmt 1: fp16 halves
 int launch_pack_bf16(const idn_facenerf_params& p, float* packed, hipStream_t s);
 int launch_mlp_bf16(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
                     const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
 int launch_mlp_bf16x3(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
+                      const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
+int launch_mlp_fp16x3(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
                       const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
 // precision dispatch for the inference forward
 int launch_mlp(int precision, const float* packed, const float* folded, const float* x, const float* rays,

@@ -19,6 +19,35 @@
 
 namespace idn {
 
+// The x3 kernel exists in two 16-bit formats, compiled from this one source (mlp_fp16x3.hip defines
+// IDN_X3_FP16 and includes it):
+//   bf16 x3: 8+8 significand bits per operand -> ~1.5e-5 on the network output; no range limit.
+//   fp16 x3: 11+11 bits -> ~5e-7, i.e. fp32-like parity at the same MFMA count, for |activations| < 6.5e4
+//            (fp16's range; beyond it the split saturates: finite but wrong).
+#ifdef IDN_X3_FP16
+#define X3_NS x3_fp16
+#define X3_KERNEL mlp_fp16x3_kernel
+#define X3_LAUNCH launch_mlp_fp16x3
+#else
+#define X3_NS x3_bf16
+#define X3_KERNEL mlp_bf16x3_kernel
+#define X3_LAUNCH launch_mlp_bf16x3
+#endif
+namespace X3_NS {
+#ifdef IDN_X3_FP16
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+// one packed word of the hi part and of the lo part from two fp32 values.  hi is rounded toward zero
+// (v_cvt_pkrtz_f16_f32, never overflows to inf); lo = x - hi is exact in fp32 and carries the next 11 bits.
+__device__ __forceinline__ void split2(float x0, float x1, float& hi_w, float& lo_w) {
+    const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const float f0 = (float)h[0], f1 = (float)h[1];
+    hi_w = __builtin_bit_cast(float, h);
+    lo_w = __builtin_bit_cast(float, __builtin_amdgcn_cvt_pkrtz(x0 - f0, x1 - f1));
+}
+#else
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
@@ -37,6 +66,9 @@ __device__ __forceinline__ void split2(float x0, float x1, float& hi_w, float& l
     hi_w = __uint_as_float(h);
     lo_w = __uint_as_float(cvt_pk_bf16(x0 - f0, x1 - f1));
 }
+#endif
+}  // namespace X3_NS
+using namespace X3_NS;
 
 // Packed activations of one 32-channel tile: two k-steps, hi and lo.
 struct BTile {
@@ -162,7 +194,7 @@ __device__ __forceinline__ void input_features(const MlpArgs& a, long Pc, int h,
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
+__global__ __launch_bounds__(256, 1) void X3_KERNEL(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     float* bias_s = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes);
@@ -275,6 +307,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs a) {
     __syncthreads();
 }
 
+#ifndef IDN_X3_FP16   // the plain-bf16 kernel is compiled once, with the bf16 x3 kernel
 // ===========================================================================================
 // Plain bf16 (IDN_PREC_BF16): one bf16 MFMA per 16 channels, weights and activations rounded to
 // bf16 once, fp32 accumulate.  ~1e-2 relative on the raw output: reserved for
@@ -506,17 +539,19 @@ int launch_mlp_bf16(const float* packed, const float* folded, const float* x, co
     return IDN_OK;
 }
 
-int launch_mlp_bf16x3(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
+#endif  // IDN_X3_FP16
+
+int X3_LAUNCH(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
                       const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s) {
     if (n_points <= 0) return IDN_OK;
     static LaunchSetup setup;
     int num_cu = 0;
     if (int e = setup.get([]() -> int {
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModeRays>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&X3_KERNEL<kModeRays>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModeX>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&X3_KERNEL<kModeX>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16x3_kernel<kModePts>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&X3_KERNEL<kModePts>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
             return IDN_OK;
         }, &num_cu))
@@ -526,11 +561,11 @@ int launch_mlp_bf16x3(const float* packed, const float* folded, const float* x, 
     MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, nullptr, 0};
     ProfScope prof(s, n_points);
     if (x)
-        hipLaunchKernelGGL((mlp_bf16x3_kernel<kModeX>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((X3_KERNEL<kModeX>), dim3(grid), dim3(256), kMlpLds, s, a);
     else if (pts)
-        hipLaunchKernelGGL((mlp_bf16x3_kernel<kModePts>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((X3_KERNEL<kModePts>), dim3(grid), dim3(256), kMlpLds, s, a);
     else
-        hipLaunchKernelGGL((mlp_bf16x3_kernel<kModeRays>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((X3_KERNEL<kModeRays>), dim3(grid), dim3(256), kMlpLds, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

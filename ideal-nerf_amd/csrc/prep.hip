@@ -5,6 +5,7 @@
 // that is constant per frame: the broadcast [aud | expr/3 | latent] columns of layers 0 and 5
 // and the expr/3 columns of views_linears.0 contribute W[:, cols] . vector, a bias.
 #include "idn_internal.h"
+#include <hip/hip_fp16.h>
 
 namespace idn {
 
@@ -54,7 +55,10 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
     const unsigned u = __float_as_uint(x);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;  // finite inputs only (weights)
 }
-__global__ void pack_bf16x3_kernel(PackDesc d, uint4* out) {
+// fmt 0: bf16 halves (round to nearest even); fmt 1: fp16 halves (IDN_PREC_FP16X3)
+__device__ __forceinline__ unsigned f16_rne(float x) { return (unsigned)__half_as_ushort(__float2half_rn(x)); }
+__device__ __forceinline__ float f16_to_f32(unsigned b) { return __half2float(__ushort_as_half((unsigned short)b)); }
+__global__ void pack_bf16x3_kernel(PackDesc d, uint4* out, int fmt) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= kStreamFrags * 64) return;
     const int f = gid >> 6, lane = gid & 63;
@@ -77,8 +81,14 @@ __global__ void pack_bf16x3_kernel(PackDesc d, uint4* out) {
                 if (n < L.rows) v = L.w[(long)n * L.ld + L.col0[src] + k];
                 else if (L.w_extra && n == L.extra_at && src == 0) v = L.w_extra[k];
             }
-            const unsigned hi = bf16_rne(v);
-            const unsigned bits = part == 0 ? hi : bf16_rne(v - __uint_as_float(hi << 16));
+            unsigned bits;
+            if (fmt == 0) {
+                const unsigned hi = bf16_rne(v);
+                bits = part == 0 ? hi : bf16_rne(v - __uint_as_float(hi << 16));
+            } else {
+                const unsigned hi = f16_rne(v);
+                bits = part == 0 ? hi : f16_rne(v - f16_to_f32(hi));
+            }
             w[j >> 1] |= bits << (16 * (j & 1));
         }
     }
@@ -125,11 +135,11 @@ int launch_pack_bf16(const idn_facenerf_params& p, float* packed, hipStream_t s)
     return IDN_OK;
 }
 
-int launch_pack_bf16x3(const idn_facenerf_params& p, float* packed, hipStream_t s) {
+int launch_pack_bf16x3(const idn_facenerf_params& p, float* packed, hipStream_t s, int fmt) {
     PackDesc d;
     fill_pack_desc(p, d);
     const int total = kStreamFrags * 64;
-    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d, reinterpret_cast<uint4*>(packed));
+    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d, reinterpret_cast<uint4*>(packed), fmt);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

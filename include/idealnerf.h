@@ -52,6 +52,8 @@ extern "C" {
 #define IDN_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains */
 #define IDN_PREC_BF16X3 1 /* 3 bf16 MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulate */
 #define IDN_PREC_BF16 2   /* plain bf16 MFMA, fp32 accumulate (BASELINE config 5 only) */
+#define IDN_PREC_FP16X3 3 /* 3 fp16 MFMAs per product (11+11 significand bits per operand): ~5e-7 on the
+                             network output at the bf16x3 speed; activations must stay below 6.5e4 */
 
 int idealnerf_version(void);
 const char* idealnerf_last_error(void);

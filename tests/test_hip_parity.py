@@ -1139,3 +1139,55 @@ def test_random_scenes_fp32_and_mixed_vs_oracle(idn, dev, seed):
             assert bool(torch.isfinite(out[k]).all()), (mode, k)
         assert rel_err(out["rgb_map"], ref["rgb_map"]) < RGB_TOL, mode
         assert rel_err(out["rgb0"], ref["rgb0"]) < RGB_TOL, mode
+
+
+# --------------------------------------------------------------------------- fp16x3 arithmetic mode
+FP16X3 = 3  # IDN_PREC_FP16X3
+
+
+def test_fp16x3_facenerf_golden_and_ragged(idn, dev, golden):
+    """Three fp16 MFMAs per product (11+11 significand bits per operand): fp32-like error on the network
+    output at the bf16x3 speed, for activations inside fp16's range."""
+    g = golden("facenerf")
+    for name, v in (("c235", dict(dim_aud=64, dim_expr=76, dim_latent=32)), ("c169", dict(dim_aud=106, dim_expr=0, dim_latent=0))):
+        dims = oracle.facenerf_dims(**v)
+        sd = {k: t.to(dev).contiguous() for k, t in oracle.xavier_facenerf_params(11, dims).items()}
+        ps = idn.ops.params_struct(sd, dims["dim_aud"], dims["dim_expr"], dims["dim_latent"])
+        opt = lambda k: T(g[k]).to(dev) if k in g else None
+        folded = idn.ops.fold_conditioning(ps, T(g[name + "_aud"]).to(dev), opt(name + "_expr"), opt(name + "_latent"), dev)
+        out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, FP16X3), folded, T(g[name + "_x"]).to(dev), FP16X3)
+        assert rel_err(out, g[name + "_out"]) < 5e-6, name
+    dims = oracle.facenerf_dims()
+    params = scale_sigma(oracle.xavier_facenerf_params(5, dims), 30.0, 0.1)
+    for n in (1, 130, 4099):
+        rs = np.random.RandomState(n)
+        x = T(rs.uniform(-1, 1, size=(n, 90)).astype(np.float32))
+        aud, expr, lat = (T(rs.standard_normal(k).astype(np.float32)) for k in (64, 76, 32))
+        with torch.no_grad():
+            ref = oracle.facenerf_forward(params, x, aud, expr, lat, dims)
+        sd = {k: t.to(dev).contiguous() for k, t in params.items()}
+        ps = idn.ops.params_struct(sd, 64, 76, 32)
+        out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, FP16X3),
+                                   idn.ops.fold_conditioning(ps, aud.to(dev), expr.to(dev), lat.to(dev), dev), x.to(dev), FP16X3)
+        assert rel_err(out, ref) < 1e-5, n
+
+
+def test_fp16x3_render_frame32_golden(idn, dev, golden):
+    g = golden("frame32")
+    dims = oracle.facenerf_dims()
+    syn = oracle.synthetic_frame(32, 32, seed=0, dims=dims)
+    cond = [t.to(dev) for t in (syn["aud"], syn["expr"], syn["latent"])]
+    packs = []
+    for seed in (2, 3):
+        sd = {k: t.to(dev).contiguous() for k, t in scale_sigma(oracle.xavier_facenerf_params(seed, dims)).items()}
+        ps = idn.ops.params_struct(sd, 64, 76, 32)
+        packs.append((idn.ops.pack_weights(ps, dev, FP16X3), idn.ops.fold_conditioning(ps, *cond, dev), sd))
+    rays = idn.ops.frame_rays(syn["c2w"], 32, 32, syn["focal"], NEAR, FAR, device=dev)
+    out = idn.ops.render_rays_fwd(rays, syn["bc"].reshape(-1, 3).to(dev), packs[0][0], packs[0][1], packs[1][0], packs[1][1],
+                                  torch.linspace(0.0, 1.0, 64).to(dev), torch.linspace(0.0, 1.0, 128).to(dev), 128,
+                                  taps=True, precision=FP16X3)
+    e = rel_err(out["rgb_map"], g["rgb"].reshape(-1, 3))
+    flips = (out["tap_inds"].cpu().numpy() != g["tap_inds"].astype(np.int64)).mean()
+    print(f"\nfp16x3 frame32: rgb err {e:.2e}, index flip rate {flips:.2e}")
+    assert e < RGB_TOL and rel_err(out["rgb0"], g["rgb0"].reshape(-1, 3)) < 1e-5
+    assert flips < 2e-3

@@ -25,7 +25,7 @@ def main():
     bc = syn["bc"].reshape(-1, 3).contiguous().to(dev)
     frames = {}
     with torch.no_grad():
-        for mode, (pc_, pf_) in (("f32", ("f32", "f32")), ("mixed", ("f32", "bf16x3")), ("bf16x3", ("bf16x3", "bf16x3"))):
+        for mode, (pc_, pf_) in (("f32", ("f32", "f32")), ("fp16x3", ("fp16x3", "fp16x3")), ("mixed", ("f32", "bf16x3")), ("bf16x3", ("bf16x3", "bf16x3"))):
             coarse.precision, fine.precision = pc_, pf_
             rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], device=dev)
             o = ops.render_rays_fwd(rays, bc, coarse.packed_weights(), coarse.folded_bias(aud, expr, latent), fine.packed_weights(),
