@@ -1191,3 +1191,25 @@ def test_fp16x3_render_frame32_golden(idn, dev, golden):
     print(f"\nfp16x3 frame32: rgb err {e:.2e}, index flip rate {flips:.2e}")
     assert e < RGB_TOL and rel_err(out["rgb0"], g["rgb0"].reshape(-1, 3)) < 1e-5
     assert flips < 2e-3
+
+
+def test_fp16x3_saturates_finitely_outside_fp16_range(idn, dev):
+    """fp16x3's documented limit: activations beyond fp16's range (6.5e4) make its hi/lo split saturate.  The
+    result is then wrong but finite (v_cvt_pkrtz never produces inf), and the fp32 and bf16x3 modes of the
+    same weights are unaffected -- the failure is loud in a comparison, never a NaN frame."""
+    dims = oracle.facenerf_dims()
+    params = oracle.xavier_facenerf_params(9, dims)
+    params["pts_linears.0.weight"] = params["pts_linears.0.weight"] * 3e5    # first hidden layer ~1e5
+    rs = np.random.RandomState(0)
+    x = T(rs.uniform(-1, 1, size=(256, 90)).astype(np.float32))
+    aud, expr, lat = (T(rs.standard_normal(k).astype(np.float32)) for k in (64, 76, 32))
+    with torch.no_grad():
+        ref = oracle.facenerf_forward(params, x, aud, expr, lat, dims)
+    sd = {k: t.to(dev).contiguous() for k, t in params.items()}
+    ps = idn.ops.params_struct(sd, 64, 76, 32)
+    folded = idn.ops.fold_conditioning(ps, aud.to(dev), expr.to(dev), lat.to(dev), dev)
+    outs = {name: idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, code), folded, x.to(dev), code)
+            for name, code in (("f32", 0), ("bf16x3", 1), ("fp16x3", 3))}
+    assert rel_err(outs["f32"], ref) < 1e-5 and rel_err(outs["bf16x3"], ref) < 1e-4
+    assert bool(torch.isfinite(outs["fp16x3"]).all())
+    assert rel_err(outs["fp16x3"], ref) > 1e-3     # outside its domain, and visibly so
