@@ -2,7 +2,7 @@
 """Headline benchmark: BASELINE.json configs[1] -- May HeadNeRF 512x512 full-frame
 render, N_sample=64 + N_importance=128, synthetic inputs.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           (N > 1: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one full frame through the hot path (ray generation -> coarse PE+MLP ->
@@ -26,6 +26,49 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE = 1_114_368      # algorithmic, SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2516.6   # dense bf16 MFMA: 16x the fp32 rate (1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
+
+
+def launch_ranks(n, argv, script=None, timeout=None):
+    """`python bench.py --gpus N` started as ONE plain process: start the N ranks as fresh children
+    (`python -m torch.distributed.run`, one rank per GPU, rendezvous on 127.0.0.1), relay rank 0's
+    JSON line, and return non-zero when any rank failed or no line came back.  Takes the place of the
+    reference's single-process nn.DataParallel start (NeRFs/HeadNeRF/train/distribute_nerf.py:457-466).
+    This parent never touches the GPU (no torch.cuda / HIP call precedes this function) and never
+    re-execs itself: the ranks are children, so no process that has initialised the GPU is replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    try:
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        sys.stderr.write(f"bench.py: the {n}-rank run did not finish within {timeout} s\n")
+        return 124
+    line = None
+    for ln in proc.stdout.splitlines():
+        try:
+            if "metric" in json.loads(ln):
+                line = ln
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(ln + "\n")      # anything else the ranks printed is diagnostics
+    if proc.returncode != 0:
+        sys.stderr.write(f"bench.py: a rank failed (torch.distributed.run exit code {proc.returncode})\n")
+        return proc.returncode
+    if line is None:
+        sys.stderr.write("bench.py: the ranks finished without printing a result line\n")
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 def host_cpu_share():
@@ -66,6 +109,51 @@ def cpu_baseline(syn, pc, pf, gpu_rgb_band, band_row0, n_rays=8192):
         mse = float(((gpu_rgb_band[:nrows].cpu() - ref["rgb_map"]) ** 2).mean())
         psnr = 10.0 * torch.log10(torch.tensor(1.0 / max(mse, 1e-20))).item()
     return out, psnr
+
+
+def init_ranks(need_gpu=True):
+    """(world, rank, device, backend) of this rank.  One process per GPU over RCCL ("nccl" on ROCm);
+    IDN_FORCE_DEVICE / IDN_DIST_BACKEND=gloo exist only to rehearse the N>1 path on a one-GPU box
+    (ranks sharing device 0) or without a GPU at all (--workload rendezvous)."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("IDN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    dev = None
+    if need_gpu:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    backend = None
+    if world > 1:
+        backend = os.environ.get("IDN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == world
+    return world, rank, dev, backend
+
+
+def bench_rendezvous(args):
+    """No compute: the ranks meet, exchange their row bands and rank 0 prints a line.  It is what the
+    CPU test of the launcher runs (tests/test_boundary_cpu.py), and a quick check of a node's
+    rendezvous before a real run."""
+    import torch.distributed as dist
+    from idealnerf_amd import parallel
+    world, rank, _, backend = init_ranks(need_gpu=False)
+    r0, r1 = parallel.row_band(args.size, rank, world)
+    mine = torch.tensor([r0, r1], dtype=torch.int64)
+    bands = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(bands, mine)
+    else:
+        bands = [mine]
+    if rank == 0:
+        print(json.dumps({"metric": "rendezvous", "value": float(world), "unit": "ranks", "n_gpus": args.gpus,
+                          "ranks": world, "backend": backend, "steps": args.steps, "warmup": args.warmup,
+                          "bands": [[int(b[0]), int(b[1])] for b in bands]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def bench_train(args):
@@ -127,16 +215,7 @@ def bench_torso(args):
     from idealnerf_amd.helper import RenderConfig
     from idealnerf_amd.train_torso import Network
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", int(os.environ.get("IDN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
-    torch.cuda.set_device(dev)
-    if world > 1:
-        backend = os.environ.get("IDN_DIST_BACKEND", "nccl")   # gloo only to rehearse on a one-GPU box
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    world, rank, dev, backend = init_ranks()
     H = W = args.size
     prec = args.precision if args.precision_given else "bf16"
     syn = synthetic.frame(H, W, seed=rank)   # every rank renders a different frame of the clip
@@ -186,7 +265,8 @@ def bench_torso(args):
     if rank == 0:
         samples = world * args.steps * H * W * 2 * 256
         print(json.dumps({"metric": "ray-samples/sec (head + torso composite, 64+128 pts each, whole job)", "value": samples / dt,
-                          "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "unit": "ray-samples/s", "n_gpus": world, "ranks": world, "backend": backend,
+                          "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": prec, "data": "synthetic",
                           "frames_per_s": world * args.steps / dt,
@@ -217,35 +297,30 @@ def main():
                          "the headline as `bf16x3_mode`.  mixed: fp32 coarse network (it drives the sampling) + bf16x3 fine "
                          "network, ~2x the fp32 speed inside the 1e-4 budget, measured as `mixed_mode`.  bf16 (plain, ~1e-2): "
                          "BASELINE config 5's PSNR criterion only")
-    ap.add_argument("--workload", choices=["frame", "train", "torso"], default="frame",
+    ap.add_argument("--workload", choices=["frame", "train", "torso", "rendezvous"], default="frame",
                     help="frame = BASELINE configs[1] (default, the headline metric); train = configs[2] train step; "
                          "torso = configs[4] head+torso composite frames, plain bf16, frame-parallel")
     args = ap.parse_args()
     args.precision_given = any(a.startswith("--precision") for a in sys.argv[1:]) or "IDN_PRECISION" in os.environ
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # plain `python bench.py --gpus N`: this process only starts the ranks (no GPU call before here)
+            if args.workload == "train":
+                ap.error("--workload train is a single-GPU measurement")
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
     if args.workload == "train":
         return bench_train(args)
     if args.workload == "torso":
         return bench_torso(args)
+    if args.workload == "rendezvous":
+        return bench_rendezvous(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
-    # IDN_FORCE_DEVICE / IDN_DIST_BACKEND exist only to rehearse the N>1 code path on a one-GPU box
-    # (two ranks sharing device 0 over gloo); the driver's runs use one GPU per rank over RCCL.
-    if "IDN_FORCE_DEVICE" in os.environ:
-        local_rank = int(os.environ["IDN_FORCE_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        backend = os.environ.get("IDN_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    world, rank, dev, backend = init_ranks()
 
     import idealnerf_amd
     from idealnerf_amd import ops, parallel, synthetic
@@ -335,14 +410,16 @@ def main():
                  "mixed": "idn::mlp_f32_kernel (coarse network) + idn::mlp_bf16x3_kernel (fine network); blended peak"}[args.precision]
         res = {
             "metric": "ray-samples/sec (64+128 pts, 512x512), whole job", "value": value, "unit": "ray-samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "ranks": world, "backend": backend,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)", "mixed": "f32 coarse network + bf16x3 fine network", "fp16x3": "fp16x3 (fp32 in/out, fp32 accumulate)"}[args.precision], "data": "synthetic",
             "per_gpu": value / world, "rays_per_s": value / (S + S + Ni),
             **({"soak_mismatched_frames": int(mismatched.item())} if args.soak else {}),
             "config": {"workload": f"BASELINE configs[1]: May HeadNeRF {H}x{W} full-frame render, N_sample=64 "
                                    "N_importance=128, dim_aud=64 dim_expr=76 latent=32, perturb=0",
                        "rays_per_step": H * W, "samples_per_ray": S + S + Ni,
-                       "partition": f"{world} row band(s) + RCCL all_gather of rgb tiles" if world > 1 else "single GPU"},
+                       "partition": f"{world} row band(s) + {backend} all_gather of rgb tiles" if world > 1 else "single GPU",
+                       "band_rows": [b - a for a, b in parallel.all_bands(H, world)]},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": (ach / peak) if ach else None, "traffic": traffic,

@@ -432,3 +432,79 @@ def test_clip_audio_features_match_reference_loop(golden):
     assert np.abs(out.numpy() - g["out"]).max() < 2e-6 * max(1.0, np.abs(g["out"]).max())
     with pytest.raises(ValueError):
         clip_audio_features(aud_net, att_net, torch.zeros(5, 16, 29))
+
+
+# --- the self-launching bench (`python bench.py --gpus N`, the driver's scaling command) ------------
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("idn_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_plain_start_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` started as ONE plain process (no torch.distributed.run around it):
+    the parent starts two ranks, they rendezvous over gloo (no GPU here), the flags reach the ranks and
+    rank 0's line -- and only that line -- comes back on stdout."""
+    import json
+    env = dict(os.environ, IDN_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "3",
+                        "--size", "9", "--workload", "rendezvous"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["backend"] == "gloo"
+    assert res["steps"] == 7 and res["warmup"] == 3
+    assert res["bands"] == [[0, 5], [5, 9]]
+
+
+def test_bench_launcher_propagates_a_failed_rank(tmp_path, capsys):
+    """A rank that dies makes the parent exit non-zero and print no result line; a run whose ranks all
+    succeed but print nothing is a failure too."""
+    bench = _bench_module()
+    bad = tmp_path / "bad_rank.py"
+    bad.write_text("import os, sys, json\n"
+                   "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                   "print(json.dumps({'metric': 'm', 'value': 1.0}))\n")
+    rc = bench.launch_ranks(2, [], script=str(bad), timeout=300)
+    out = capsys.readouterr()
+    assert rc != 0 and out.out.strip() == ""
+    quiet = tmp_path / "quiet_rank.py"
+    quiet.write_text("print('hello from a rank')\n")
+    rc = bench.launch_ranks(2, [], script=str(quiet), timeout=300)
+    out = capsys.readouterr()
+    assert rc == 1 and out.out.strip() == "" and "hello from a rank" in out.err
+    good = tmp_path / "good_rank.py"
+    good.write_text("import os, sys, json\n"
+                    "assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                    "if os.environ['RANK'] == '0':\n"
+                    "    print(json.dumps({'metric': 'm', 'value': 2.0, 'argv': sys.argv[1:]}))\n")
+    rc = bench.launch_ranks(2, ["--steps", "4"], script=str(good), timeout=300)
+    out = capsys.readouterr()
+    assert rc == 0
+    import json
+    assert json.loads(out.out.strip())["argv"] == ["--steps", "4"]
+
+
+def test_bench_parent_never_touches_the_gpu_before_launching():
+    """The launcher branch must run before any torch.cuda / HIP call: in the source, the WORLD_SIZE test
+    and launch_ranks() precede every `torch.cuda` use of main(), and launch_ranks itself has none."""
+    import inspect
+    bench = _bench_module()
+    src = inspect.getsource(bench.main)
+    assert src.index("launch_ranks(") < src.index("init_ranks(")
+    assert "torch.cuda" not in src[:src.index("launch_ranks(")]
+    assert "torch.cuda" not in inspect.getsource(bench.launch_ranks).split('"""')[2]
+    assert "os.exec" not in open(os.path.join(ROOT, "bench.py")).read()
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "rendezvous"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
