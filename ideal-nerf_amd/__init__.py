@@ -13,5 +13,5 @@ at the repository root makes it importable).  Layout mirrors the reference:
 __version__ = "0.1.0"
 
 from . import _lib, ops  # noqa: F401
-from .models.face_nerf import FaceNeRF, set_default_precision, set_render_precision  # noqa: F401
+from .models.face_nerf import FaceNeRF, invalidate_packed, set_default_precision, set_render_precision  # noqa: F401
 from .models.face_nerf_agg import FaceNeRFAgg  # noqa: F401

@@ -85,12 +85,26 @@ class Network(nn.Module):
 
     # ---- batchify_rays: audio_exp_nerf.py:274-288 -----------------------------------
     def batchify_rays(self, rays, bc_rgb, aud_para, poses, latent_code, expr, chunk=1024 * 32):
+        """Same results as the reference's chunk loop.  The loop exists upstream to bound the activation
+        memory of a chunk (25 KB per sample); here activations never leave registers and the C call walks
+        the rays in its own 32 768-ray passes over a fixed workspace, so a deterministic render
+        (perturb == 0: rays are independent and nothing is drawn per chunk) is ONE call whatever `chunk`
+        is -- one conditioning fold and one set of output tensors per frame instead of one per chunk.
+        With perturb > 0 the per-chunk random draws are part of the result (under `pytest` every chunk
+        re-seeds numpy, audio_exp_nerf.py:316-318), so the loop is kept."""
+        return self._batchify(rays, bc_rgb, aud_para, latent_code, expr, self.face_nerf_coarse, self.face_nerf_fine,
+                              False, chunk)
+
+    def _batchify(self, rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg, chunk):
+        training = torch.is_grad_enabled() and self.training
+        if not training and self.args.perturb == 0.:
+            return self._render(rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg)
         all_ret = {}
         for i in range(0, rays.shape[0], chunk):
-            ret = self.render_rays(rays[i:i + chunk], bc_rgb[i:i + chunk], aud_para, poses, latent_code, expr)
+            ret = self._render(rays[i:i + chunk], bc_rgb[i:i + chunk], aud_para, latent_code, expr, coarse, fine, with_fg)
             for k in ret:
                 all_ret.setdefault(k, []).append(ret[k])
-        return {k: torch.cat(v, 0) for k, v in all_ret.items()}
+        return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
 
     # ---- render_rays: audio_exp_nerf.py:290-364 -------------------------------------
     def render_rays(self, rays, bc_rgb, aud_para, poses, latent_code, expr, retraw=False, lindisp=False,
@@ -171,7 +185,14 @@ class Network(nn.Module):
 
     # ---- run_network: audio_exp_nerf.py:369-387 -------------------------------------
     def run_network(self, inputs, expr, viewdirs, aud, nerf_model, latent_code, netchunk=1024 * 64):
-        """pts [n, S, 3] + unit viewdirs [n, 3] -> raw [n, S, 4]; both encodings fused."""
+        """pts [n, S, 3] + unit viewdirs [n, 3] -> raw [n, S, 4]; both encodings fused.  Inference only:
+        with autograd on and anything upstream requiring grad this raises instead of silently returning a
+        tensor without a graph (training goes through render_rays, whose backward is built)."""
+        if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in nerf_model.parameters())
+                                        or any(t is not None and t.requires_grad for t in (aud, latent_code))):
+            raise NotImplementedError(
+                "Network.run_network carries no gradient: train through Network.render_rays / forward "
+                "(audio_exp_nerf.py:534), or call under torch.no_grad() for inference")
         with torch.no_grad():
             folded = nerf_model.folded_bias(aud, expr, latent_code)
             return ops.query_points_fwd(nerf_model.packed_weights(), folded, inputs.to(torch.float32).contiguous(),

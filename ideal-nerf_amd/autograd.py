@@ -47,12 +47,16 @@ def _grads_struct(grads):
 
 def _train_query(net, folded, rays, z):
     lib = _lib.load()
+    ops._shape(z, "z", None, None)
     n, S = z.shape
-    raw = torch.empty((n, S, 4), dtype=torch.float32, device=z.device)
-    acts = torch.empty(lib.idealnerf_train_acts_floats(n * S), dtype=torch.float32, device=z.device)
-    check(lib.idealnerf_query_rays_train_fwd(net.packed_weights("f32").data_ptr(), folded.data_ptr(), IDN_PREC_F32,
-                                             rays.data_ptr(), z.data_ptr(), n, S, raw.data_ptr(), acts.data_ptr(),
-                                             torch.cuda.current_stream().cuda_stream))
+    ops._shape(rays, "rays", n, ops.RAY_FLOATS)
+    packed = net.packed_weights("f32")
+    with ops._Launch(packed, folded, rays, z) as L:
+        raw = torch.empty((n, S, 4), dtype=torch.float32, device=z.device)
+        acts = torch.empty(lib.idealnerf_train_acts_floats(n * S), dtype=torch.float32, device=z.device)
+        check(lib.idealnerf_query_rays_train_fwd(ops._ptr(packed, "packed"), ops._ptr(folded, "folded"), IDN_PREC_F32,
+                                                 ops._ptr(rays, "rays"), ops._ptr(z, "z"), n, S, raw.data_ptr(),
+                                                 acts.data_ptr(), L.stream))
     return raw, acts
 
 
@@ -66,12 +70,18 @@ def _pass_bwd(net, aud, expr, latent, acts, raw, z, rays, bc, g_rgb, g_fg, g_lw,
     ps = net.kernel_params()
     gs = _grads_struct(grads)
     nbytes = lib.idealnerf_pass_bwd_workspace_bytes(n, S)
-    ws = _workspace(nbytes, z.device)
-    ptr = lambda t: None if t is None else t.data_ptr()
-    check(lib.idealnerf_pass_bwd(C.byref(ps), C.byref(gs), ptr(aud), ptr(expr), ptr(latent), acts.data_ptr(),
-                                 raw.data_ptr(), z.data_ptr(), rays.data_ptr(), bc.data_ptr(), n, S, ptr(g_rgb),
-                                 ptr(g_fg), ptr(g_lw), ptr(g_acc), ptr(d_aud), ptr(d_latent), ws.data_ptr(),
-                                 ws.numel(), torch.cuda.current_stream().cuda_stream))
+    for t, name, shape in ((raw, "raw", (n, S, 4)), (rays, "rays", (n, ops.RAY_FLOATS)), (bc, "bc_rgb", (n, 3)),
+                           (g_rgb, "g_rgb_map", (n, 3)), (g_fg, "g_rgb_fg", (n, 3)), (g_lw, "g_last_weight", (n,)),
+                           (g_acc, "g_acc", (n,))):
+        ops._shape(t, name, *shape)
+    ptr = ops._ptr
+    with ops._Launch(aud, expr, latent, acts, raw, z, rays, bc, g_rgb, g_fg, g_lw, g_acc, d_aud, d_latent,
+                     *grads.values()) as L:
+        ws = _workspace(nbytes, z.device)
+        check(lib.idealnerf_pass_bwd(C.byref(ps), C.byref(gs), ptr(aud), ptr(expr), ptr(latent), ptr(acts),
+                                     ptr(raw), ptr(z), ptr(rays), ptr(bc), n, S, ptr(g_rgb),
+                                     ptr(g_fg), ptr(g_lw), ptr(g_acc), ptr(d_aud), ptr(d_latent), ws.data_ptr(),
+                                     ws.numel(), L.stream))
     return grads
 
 

@@ -184,6 +184,16 @@ int idealnerf_sample_pdf_fwd(const float* z, const float* weights, const float* 
                              inds, cdf, z_fine, z_std, (hipStream_t)stream);
 }
 
+int idealnerf_sample_pdf_bins_fwd(const float* bins, const float* weights, const float* u, int u_per_ray,
+                                  int64_t n_rays, int n_bins, int n_importance, float* z_samples, int64_t* inds,
+                                  float* cdf, void* stream) {
+    if (n_rays < 0) return fail(IDN_EINVAL, "n_rays < 0");
+    if (n_rays == 0) return IDN_OK;
+    if (!bins || !weights || !u) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_sample_pdf(nullptr, weights, nullptr, bins, u, u_per_ray, n_rays, n_bins + 1, n_importance, z_samples,
+                             inds, cdf, nullptr, nullptr, (hipStream_t)stream);
+}
+
 int idealnerf_invert_cdf(const float* cdf, const float* bins, const float* u, int u_per_ray, int64_t n_rays,
                          int n_bins, int n_importance, float* z_samples, int64_t* inds, void* stream) {
     if (n_rays < 0) return fail(IDN_EINVAL, "n_rays < 0");

@@ -277,16 +277,16 @@ int launch_composite(const float* raw, const float* z, const float* rays, const 
 // a7 + a8: sample_pdf (helper.py:269-313) and sorted merge (audio_exp_nerf.py:347-349)
 //
 // Per ray (one wave): bins / cdf staged in LDS, inverse CDF by binary search
-// (searchsorted right=True: inds = #{k : cdf[k] <= u}), merge by rank counting (values
-// only are kept, so any stable total order gives torch.sort's values).
+// (searchsorted right=True: inds = #{k : cdf[k] <= u}), merge of the two depth lists by rank
+// (values only are kept, so any total order gives torch.sort's values).
 // ---------------------------------------------------------------------------
 constexpr int kMaxBins = 256;   // S - 1 <= 255
 constexpr int kMaxNi = 256;
 constexpr int kMaxFine = 512;
 
 struct SampleArgs {
-    const float* z;        // [n,S] coarse depths (null when cdf_in/bins_in are given)
-    const float* weights;  // [n,S]
+    const float* z;        // [n,S] coarse depths (null when bins_in is given)
+    const float* weights;  // [n,S] (the kernel uses [:,1:-1]) or, with bins_in, [n,nb-1] as helper.sample_pdf takes them
     const float* cdf_in;   // [n,nb] optional: skip the pdf/cdf stage (bit-exact boundary)
     const float* bins_in;  // [n,nb]
     const float* u;
@@ -299,6 +299,41 @@ struct SampleArgs {
     float* z_fine;
     float* z_std;
 };
+
+// torch.sum(x, -1) of a contiguous fp32 row as PyTorch's CPU kernel evaluates it (ATen
+// native/cpu/SumKernel.cpp: vectorized_inner_sum -> row_sum -> multi_row_sum, the AVX2 build that
+// is dispatched on AVX2 and AVX512 hosts alike): 8-lane vectors; vector i goes to accumulator i&3
+// while i < 4*(nv/4), the remaining vectors to accumulator 0; accumulators 1..3 are added to 0 in
+// turn; the scalar tail x[8*nv..] is summed from zero, then the 8 lanes are added one by one.
+// multi_row_sum only starts cascading at 16 rows of 4 vectors (K >= 512), above the sizes taken here.
+// This is the sum that normalises the pdf (helper.py:272) and therefore decides importance indices:
+// reproducing its order makes cdf and inds bit-identical to the reference for identical weights
+// (tests/golden/sample_pdf.npz, frame32.npz).  w: this wave's row in LDS.
+__device__ __forceinline__ float aten_row_sum(const float* w, int K, int lane) {
+    const int nv = K >> 3, ni = nv >> 2;
+    const int acc_id = (lane >> 3) & 3, j = lane & 7;
+    float acc = 0.0f;
+    for (int i = 0; i < ni; ++i) acc = acc + w[((i * 4 + acc_id) << 3) + j];
+    if (acc_id == 0)
+        for (int i = ni * 4; i < nv; ++i) acc = acc + w[(i << 3) + j];
+    const float a1 = __shfl(acc, j + 8, 64), a2 = __shfl(acc, j + 16, 64), a3 = __shfl(acc, j + 24, 64);
+    acc = ((acc + a1) + a2) + a3;  // meaningful in lanes 0..7
+    float total = 0.0f;
+    for (int k = nv << 3; k < K; ++k) total = total + w[k];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) total = total + __shfl(acc, q, 64);
+    return total;
+}
+
+// Ascending total order with NaN last (torch.sort's): a before b?
+__device__ __forceinline__ bool sort_lt(float a, float b) { return a < b || (b != b && a == a); }
+__device__ __forceinline__ bool sort_eq(float a, float b) { return a == b || (a != a && b != b); }
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes of this wave are done
+}
 
 __global__ __launch_bounds__(256) void sample_pdf_kernel(SampleArgs a) {
     __shared__ float s_cdf[4][kMaxBins];
@@ -318,20 +353,26 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SampleArgs a) {
             bins[k] = a.bins_in[ray * nb + k];
         }
     } else {
-        const float* zr = a.z + ray * a.S;
-        const float* wr = a.weights + ray * a.S;
-        // bins = z midpoints; w' = w[1:-1] + 1e-5; lane l owns pdf entries l*4 .. l*4+3
-        for (int k = lane; k < nb; k += 64) bins[k] = 0.5f * (zr[k + 1] + zr[k]);
-        const int np = a.S - 2;
+        const int np = nb - 1;
+        const float* wr;
+        if (a.bins_in) {  // helper.sample_pdf(bins, weights, ...): the caller's own bins and weights[n, nb-1]
+            for (int k = lane; k < nb; k += 64) bins[k] = a.bins_in[ray * nb + k];
+            wr = a.weights + ray * np;
+        } else {          // bins = z midpoints; weights[:, 1:-1] (audio_exp_nerf.py:340-342)
+            const float* zr = a.z + ray * a.S;
+            for (int k = lane; k < nb; k += 64) bins[k] = 0.5f * (zr[k + 1] + zr[k]);
+            wr = a.weights + ray * a.S + 1;
+        }
+        // w' = w + 1e-5; lane l owns pdf entries l*4 .. l*4+3
         float wp[4];
-        double loc = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = lane * 4 + i;
-            wp[i] = (k < np) ? wr[k + 1] + 1e-5f : 0.0f;
-            loc += (double)wp[i];
+            wp[i] = (k < np) ? wr[k] + 1e-5f : 0.0f;
+            if (k < np) val[k] = wp[i];
         }
-        const float total = (float)wave_sum_d(loc);  // torch.sum(weights, -1)
+        wave_lds_fence();
+        const float total = aten_row_sum(val, np, lane);  // torch.sum(weights, -1, keepdim=True)
         double pl = 0.0;
         float pdf[4];
 #pragma unroll
@@ -349,9 +390,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SampleArgs a) {
             if (k < np) cdf[k + 1] = (float)run;  // cumsum output rounded per element
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes of this wave are done
+    wave_lds_fence();
     if (a.cdf_out)
         for (int k = lane; k < nb; k += 64) a.cdf_out[ray * nb + k] = cdf[k];
 
@@ -395,25 +434,51 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SampleArgs a) {
         m2 = wave_sum_d(m2);
         if (lane == 0) a.z_std[ray] = (float)sqrt(m2 / (double)a.Ni);
     }
-    // ---- z_fine = sort(cat[z_coarse, z_samples])
+    // ---- z_fine = sort(cat[z_coarse, z_samples]).  Element e of the concatenation goes to slot
+    // rank(e) = #{j : val[j] before val[e], ties by position}.  Both halves are normally sorted
+    // already (coarse depths always; the samples whenever u is sorted, i.e. perturb == 0), and then
+    // the rank is the element's own position plus one binary search in the other half; otherwise
+    // (random u) every element is counted against all others.  Either way the slots are those of a
+    // stable sort, so the output does not depend on which branch ran.
     if (a.z_fine) {
         const int nf = a.S + a.Ni;
         const float* zr = a.z + ray * a.S;
+        wave_lds_fence();  // the row sum's reads of val are done
         for (int k = lane; k < a.S; k += 64) val[k] = zr[k];
 #pragma unroll
         for (int ii = 0; ii < kMaxNi / 64; ++ii)
             if (ii * 64 + lane < a.Ni) val[a.S + ii * 64 + lane] = zsv[ii];
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        for (int e = lane; e < nf; e += 64) {
-            const float v = val[e];
-            int rank = 0;
-            for (int j = 0; j < nf; ++j) {
-                const float o = val[j];
-                rank += (o < v || (o == v && j < e)) ? 1 : 0;
+        wave_lds_fence();
+        bool ordered = true;
+        for (int e = lane; e < nf; e += 64)
+            if (e + 1 < nf && e + 1 != a.S && sort_lt(val[e + 1], val[e])) ordered = false;
+        if (__all(ordered)) {
+            for (int e = lane; e < nf; e += 64) {
+                const float v = val[e];
+                const bool first = e < a.S;
+                // other half: first-half elements count strictly smaller ones, second-half elements also equal ones
+                int lo = first ? a.S : 0, hi = first ? nf : a.S;
+                const int base = lo;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const float o = val[mid];
+                    const bool before = first ? sort_lt(o, v) : (sort_lt(o, v) || sort_eq(o, v));
+                    if (before) lo = mid + 1;
+                    else hi = mid;
+                }
+                const int rank = (first ? e : e - a.S) + (lo - base);
+                a.z_fine[ray * nf + rank] = v;
             }
-            a.z_fine[ray * nf + rank] = v;
+        } else {
+            for (int e = lane; e < nf; e += 64) {
+                const float v = val[e];
+                int rank = 0;
+                for (int j = 0; j < nf; ++j) {
+                    const float o = val[j];
+                    rank += (sort_lt(o, v) || (sort_eq(o, v) && j < e)) ? 1 : 0;
+                }
+                a.z_fine[ray * nf + rank] = v;
+            }
         }
     }
 }
@@ -426,6 +491,7 @@ int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in,
     if (nb < 2 || nb > kMaxBins - 1) return fail(IDN_EUNSUPPORTED, "sample_pdf: %d bins outside [2, %d]", nb, kMaxBins - 1);
     if (Ni < 1 || Ni > kMaxNi) return fail(IDN_EUNSUPPORTED, "sample_pdf: n_importance %d outside [1, %d]", Ni, kMaxNi);
     if (S + Ni > kMaxFine) return fail(IDN_EUNSUPPORTED, "sample_pdf: n_samples + n_importance > %d", kMaxFine);
+    if (z_fine && !z) return fail(IDN_EINVAL, "sample_pdf: the merged depths need the coarse depths z");
     SampleArgs a{z, weights, cdf_in, bins_in, u, u_per_ray, (long)n_rays, S, Ni, nb, z_samples, inds, cdf_out, z_fine, z_std};
     hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, s, a);
     IDN_HIP_CHECK(hipGetLastError());

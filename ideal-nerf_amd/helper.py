@@ -116,8 +116,8 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
             u = torch.Tensor(np.random.rand(n, N_samples)).to(dev)
         else:
             u = torch.rand((n, N_samples), device=dev)
-    w = weights + 1e-5
-    pdf = w / torch.sum(w, -1, keepdim=True)
-    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
-    zs, _ = ops.invert_cdf(cdf.contiguous(), bins.contiguous(), u.contiguous())
-    return zs
+    # pdf, cdf and the inversion all run in the kernel Network.render_rays uses (torch.sum in ATen's CPU
+    # order, fp64 cumsum): the standalone helper and the renderer agree bit for bit on cdf and indices
+    o = ops.sample_pdf_bins_fwd(bins.to(torch.float32).contiguous(), weights.to(torch.float32).contiguous(),
+                                u.to(torch.float32).contiguous())
+    return o["z_samples"]

@@ -33,6 +33,14 @@ def set_render_precision(network, mode: str):
             raise ValueError(f"precision must be one of {sorted(PRECISIONS) + ['mixed']}")
 
 
+def invalidate_packed(module):
+    """Drop the cached weight streams of every FaceNeRF under `module` (needed only after writes through
+    ``.data``, which PyTorch's version counters do not see)."""
+    for m in module.modules():
+        if isinstance(m, FaceNeRF):
+            m.invalidate_packed()
+
+
 def set_default_precision(name: str):
     """Arithmetic of the MLP contraction for modules created afterwards: "f32" (exact fp32
     MFMA), "bf16x3" (three bf16 MFMAs per product, ~1.5e-5 relative on the output) or "bf16"
@@ -71,6 +79,28 @@ class FaceNeRF(nn.Module):
     # -- kernel-side views of the parameters ------------------------------------------
     def _param_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def invalidate_packed(self):
+        """Drop the cached MFMA weight streams.  They are keyed on (storage, autograd version) of every
+        parameter, which optimizers, ``copy_`` and ``load_state_dict`` bump -- but writes through ``.data``
+        (``p.data.add_()``, EMA swaps, weight clipping, ``init_weights``' bias fill) do NOT.  After such a
+        write call this (or ``idealnerf_amd.invalidate_packed(network)``); ``train()`` / ``eval()``,
+        ``load_state_dict`` and ``.to()`` call it themselves.  The folded biases are recomputed per call
+        and need nothing."""
+        self._packed.clear()
+        self._packed_key.clear()
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._apply(fn, *args, **kwargs)
 
     def kernel_params(self):
         sd = {k: v for k, v in self.named_parameters()}

@@ -1,14 +1,19 @@
 """Tensor-level entry points over the C ABI.  torch is plumbing here: device memory,
-the current HIP stream and nothing else.  Every function requires CUDA (ROCm) fp32
-contiguous tensors and raises otherwise -- no silent fallback.
+the HIP stream of the tensors' device and nothing else.  Every function requires CUDA
+(ROCm) fp32 contiguous tensors of the documented shapes, all on ONE device, and raises
+``IdealNerfError`` otherwise -- before the C call, and with no silent fallback.  The launch
+happens on the tensors' own device and on that device's current stream, whatever the
+process-wide current device is (``Network.to('cuda:1')`` without ``set_device(1)`` is legal,
+as it is for the reference's torch ops).
 """
+import contextlib
 import ctypes as C
 from typing import Dict, Optional
 
 import torch
 
 from . import _lib
-from ._lib import IDN_PREC_F32, IdealNerfError, check
+from ._lib import IDN_PREC_F32, RAY_FLOATS, IdealNerfError, check
 
 PTS_CH, VIEWS_CH, W_HID = 63, 27, 256
 
@@ -25,8 +30,58 @@ def _ptr(t: Optional[torch.Tensor], name="tensor", dtype=torch.float32):
     return t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _shape(t: Optional[torch.Tensor], name: str, *shape):
+    """t must have exactly this shape (None = any size in that position)."""
+    if t is None:
+        return
+    got = tuple(t.shape)
+    if len(got) != len(shape) or any(s is not None and int(s) != g for s, g in zip(shape, got)):
+        want = "[" + ", ".join("*" if s is None else str(int(s)) for s in shape) + "]"
+        raise IdealNerfError(f"{name} must be {want}, got {list(got)}")
+
+
+class _Launch:
+    """One C call: every tensor argument on one GPU; that GPU current for the duration of the call
+    (the library launches on the calling thread's current HIP device) and its current stream."""
+
+    def __init__(self, *tensors, device=None):
+        devs = {t.device for t in tensors if t is not None and t.is_cuda}
+        if device is not None:
+            d = torch.device(device)
+            if d.type != "cuda":
+                raise IdealNerfError(f"the HIP path renders on the GPU (got device {device}); there is no CPU fallback")
+            devs.add(torch.device("cuda", torch.cuda.current_device() if d.index is None else d.index))
+        if len(devs) > 1:
+            raise IdealNerfError("all tensors of one call must live on the same GPU, got " +
+                                 ", ".join(sorted(str(d) for d in devs)))
+        self.device = devs.pop() if devs else None
+        self._ctx = contextlib.nullcontext()
+
+    def __enter__(self):
+        if self.device is not None:
+            self._ctx = torch.cuda.device(self.device)
+            self._ctx.__enter__()
+            self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        else:   # only CPU tensors: let _ptr raise the "must live on the GPU" error
+            self.stream = None
+        return self
+
+    def __exit__(self, *exc):
+        return self._ctx.__exit__(*exc)
+
+
+def _precision(precision):
+    if precision not in (_lib.IDN_PREC_F32, _lib.IDN_PREC_BF16X3, _lib.IDN_PREC_BF16, _lib.IDN_PREC_FP16X3):
+        raise IdealNerfError(f"unknown precision code {precision}")
+    return int(precision)
+
+
+def _net_buffers(lib, packed, folded, precision, which=""):
+    """The two per-network device buffers must have the sizes the kernels walk."""
+    if packed is not None:
+        _shape(packed, f"packed{which}", lib.idealnerf_packed_weight_floats(_precision(precision)))
+    if folded is not None:
+        _shape(folded, f"folded{which}", lib.idealnerf_folded_bias_floats())
 
 
 def params_struct(sd: Dict[str, torch.Tensor], dim_aud: int, dim_expr: int, dim_latent: int, prefix: str = ""):
@@ -59,58 +114,78 @@ def params_struct(sd: Dict[str, torch.Tensor], dim_aud: int, dim_expr: int, dim_
 
 
 def pack_weights(p, device, precision=IDN_PREC_F32) -> torch.Tensor:
+    """`p` holds raw addresses: the caller (FaceNeRF.packed_weights) guarantees they live on `device`."""
     lib = _lib.load()
-    out = torch.empty(lib.idealnerf_packed_weight_floats(precision), dtype=torch.float32, device=device)
-    check(lib.idealnerf_pack_weights(C.byref(p), precision, out.data_ptr(), _stream()))
+    with _Launch(device=device) as L:
+        out = torch.empty(lib.idealnerf_packed_weight_floats(_precision(precision)), dtype=torch.float32, device=L.device)
+        check(lib.idealnerf_pack_weights(C.byref(p), precision, out.data_ptr(), L.stream))
     return out
 
 
 def fold_conditioning(p, aud, expr, latent, device) -> torch.Tensor:
     lib = _lib.load()
-    out = torch.empty(lib.idealnerf_folded_bias_floats(), dtype=torch.float32, device=device)
-    check(lib.idealnerf_fold_conditioning(C.byref(p), _ptr(aud, "aud"), _ptr(expr, "expr"), _ptr(latent, "latent"),
-                                          out.data_ptr(), _stream()))
+    _shape(aud, "aud", p.dim_aud)
+    _shape(expr, "expr", p.dim_expr)
+    _shape(latent, "latent", p.dim_latent)
+    if aud is None and p.dim_aud:
+        raise IdealNerfError(f"aud is None but the network was built with dim_aud={p.dim_aud}")
+    with _Launch(aud, expr, latent, device=device) as L:
+        out = torch.empty(lib.idealnerf_folded_bias_floats(), dtype=torch.float32, device=L.device)
+        check(lib.idealnerf_fold_conditioning(C.byref(p), _ptr(aud, "aud"), _ptr(expr, "expr"), _ptr(latent, "latent"),
+                                              out.data_ptr(), L.stream))
     return out
 
 
 def facenerf_fwd(packed, folded, x, precision=IDN_PREC_F32) -> torch.Tensor:
     lib = _lib.load()
-    if x.dim() != 2 or x.shape[1] != PTS_CH + VIEWS_CH:
-        raise IdealNerfError(f"x must be [N, {PTS_CH + VIEWS_CH}], got {tuple(x.shape)}")
-    out = torch.empty((x.shape[0], 4), dtype=torch.float32, device=x.device)
-    check(lib.idealnerf_facenerf_fwd(_ptr(packed), _ptr(folded), precision, _ptr(x, "x"), x.shape[0],
-                                     out.data_ptr(), _stream()))
+    _shape(x, "x", None, PTS_CH + VIEWS_CH)
+    _net_buffers(lib, packed, folded, precision)
+    with _Launch(packed, folded, x) as L:
+        out = torch.empty((x.shape[0], 4), dtype=torch.float32, device=x.device)
+        check(lib.idealnerf_facenerf_fwd(_ptr(packed, "packed"), _ptr(folded, "folded"), precision, _ptr(x, "x"),
+                                         x.shape[0], out.data_ptr(), L.stream))
     return out
 
 
 def query_rays_fwd(packed, folded, rays, z, precision=IDN_PREC_F32) -> torch.Tensor:
     lib = _lib.load()
+    _shape(z, "z", None, None)
     n, S = z.shape
-    raw = torch.empty((n, S, 4), dtype=torch.float32, device=z.device)
-    check(lib.idealnerf_query_rays_fwd(_ptr(packed), _ptr(folded), precision, _ptr(rays, "rays"), _ptr(z, "z"), n, S,
-                                       raw.data_ptr(), _stream()))
+    _shape(rays, "rays", n, RAY_FLOATS)
+    _net_buffers(lib, packed, folded, precision)
+    with _Launch(packed, folded, rays, z) as L:
+        raw = torch.empty((n, S, 4), dtype=torch.float32, device=z.device)
+        check(lib.idealnerf_query_rays_fwd(_ptr(packed, "packed"), _ptr(folded, "folded"), precision, _ptr(rays, "rays"),
+                                           _ptr(z, "z"), n, S, raw.data_ptr(), L.stream))
     return raw
 
 
 def query_points_fwd(packed, folded, pts, viewdirs, precision=IDN_PREC_F32) -> torch.Tensor:
     lib = _lib.load()
+    _shape(pts, "pts", None, None, 3)
     n, S, _ = pts.shape
-    raw = torch.empty((n, S, 4), dtype=torch.float32, device=pts.device)
-    check(lib.idealnerf_query_points_fwd(_ptr(packed), _ptr(folded), precision, _ptr(pts, "pts"),
-                                         _ptr(viewdirs, "viewdirs"), n, S, raw.data_ptr(), _stream()))
+    _shape(viewdirs, "viewdirs", n, 3)
+    _net_buffers(lib, packed, folded, precision)
+    with _Launch(packed, folded, pts, viewdirs) as L:
+        raw = torch.empty((n, S, 4), dtype=torch.float32, device=pts.device)
+        check(lib.idealnerf_query_points_fwd(_ptr(packed, "packed"), _ptr(folded, "folded"), precision, _ptr(pts, "pts"),
+                                             _ptr(viewdirs, "viewdirs"), n, S, raw.data_ptr(), L.stream))
     return raw
 
 
 def frame_rays(c2w, H, W, focal, near, far, row0=0, nrows=None, cx=None, cy=None, device="cuda") -> torch.Tensor:
     lib = _lib.load()
-    if torch.device(device).type != "cuda":
-        raise IdealNerfError(f"frame_rays renders on the GPU (got device {device}); the HIP path has no CPU fallback")
     nrows = H - row0 if nrows is None else nrows
+    if not (0 <= row0 and 0 <= nrows and row0 + nrows <= H and W > 0):
+        raise IdealNerfError(f"rows [{row0}, {row0 + nrows}) are outside a {H}x{W} frame")
+    if tuple(c2w.shape[-2:]) not in ((3, 4), (4, 4)) or c2w.dim() != 2:
+        raise IdealNerfError(f"c2w must be [3, 4] or [4, 4], got {list(c2w.shape)}")
     m = (C.c_float * 12)(*[float(v) for v in c2w[:3, :4].reshape(-1).tolist()])
-    out = torch.empty((nrows * W, _lib.RAY_FLOATS), dtype=torch.float32, device=device)
-    check(lib.idealnerf_frame_rays(m, H, W, float(focal), -1.0 if cx is None else float(cx),
-                                   -1.0 if cy is None else float(cy), float(near), float(far), row0, nrows,
-                                   out.data_ptr(), _stream()))
+    with _Launch(device=device) as L:
+        out = torch.empty((nrows * W, RAY_FLOATS), dtype=torch.float32, device=L.device)
+        check(lib.idealnerf_frame_rays(m, H, W, float(focal), -1.0 if cx is None else float(cx),
+                                       -1.0 if cy is None else float(cy), float(near), float(far), row0, nrows,
+                                       out.data_ptr(), L.stream))
     return out
 
 
@@ -120,72 +195,120 @@ def to8b(rgb, swap_rb=False, nonfinite_flag=None) -> torch.Tensor:
     lib = _lib.load()
     if rgb.shape[-1] != 3:
         raise IdealNerfError(f"to8b expects [..., 3], got {tuple(rgb.shape)}")
-    out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
-    if nonfinite_flag is not None and (nonfinite_flag.dtype != torch.int32 or not nonfinite_flag.is_cuda):
+    if nonfinite_flag is not None and (nonfinite_flag.dtype != torch.int32 or not nonfinite_flag.is_cuda
+                                       or nonfinite_flag.numel() < 1):
         raise IdealNerfError("nonfinite_flag must be an int32 device tensor")
-    check(lib.idealnerf_to8b(_ptr(rgb, "rgb"), rgb.numel() // 3, int(bool(swap_rb)), out.data_ptr(),
-                             nonfinite_flag.data_ptr() if nonfinite_flag is not None else None, _stream()))
+    with _Launch(rgb, nonfinite_flag) as L:
+        out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+        check(lib.idealnerf_to8b(_ptr(rgb, "rgb"), rgb.numel() // 3, int(bool(swap_rb)), out.data_ptr(),
+                                 nonfinite_flag.data_ptr() if nonfinite_flag is not None else None, L.stream))
     return out
 
 
 def coarse_depths(rays, t_vals, t_rand=None) -> torch.Tensor:
     lib = _lib.load()
+    _shape(rays, "rays", None, RAY_FLOATS)
+    _shape(t_vals, "t_vals", None)
     n, S = rays.shape[0], t_vals.shape[0]
-    z = torch.empty((n, S), dtype=torch.float32, device=rays.device)
-    check(lib.idealnerf_coarse_depths(_ptr(rays, "rays"), _ptr(t_vals, "t_vals"), _ptr(t_rand, "t_rand"), n, S,
-                                      z.data_ptr(), _stream()))
+    _shape(t_rand, "t_rand", n, S)
+    with _Launch(rays, t_vals, t_rand) as L:
+        z = torch.empty((n, S), dtype=torch.float32, device=rays.device)
+        check(lib.idealnerf_coarse_depths(_ptr(rays, "rays"), _ptr(t_vals, "t_vals"), _ptr(t_rand, "t_rand"), n, S,
+                                          z.data_ptr(), L.stream))
     return z
 
 
 def composite_fwd(raw, z, rays, bc_rgb, with_fg=False, with_weights=True) -> Dict[str, torch.Tensor]:
     lib = _lib.load()
+    _shape(z, "z", None, None)
     n, S = z.shape
+    _shape(raw, "raw", n, S, 4)
+    _shape(rays, "rays", n, RAY_FLOATS)
+    _shape(bc_rgb, "bc_rgb", n, 3)
     dev = z.device
-    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    o = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n), depth_map=new(n), last_weight=new(n))
-    if with_weights:
-        o["weights"] = new(n, S)
-    if with_fg:
-        o["rgb_fg"] = new(n, 3)
-    co = _lib.CompositeOut(**{k: v.data_ptr() for k, v in o.items()})
-    check(lib.idealnerf_composite_fwd(_ptr(raw, "raw"), _ptr(z, "z"), _ptr(rays, "rays"), _ptr(bc_rgb, "bc_rgb"), n, S,
-                                      C.byref(co), _stream()))
+    with _Launch(raw, z, rays, bc_rgb) as L:
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        o = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n), depth_map=new(n), last_weight=new(n))
+        if with_weights:
+            o["weights"] = new(n, S)
+        if with_fg:
+            o["rgb_fg"] = new(n, 3)
+        co = _lib.CompositeOut(**{k: v.data_ptr() for k, v in o.items()})
+        check(lib.idealnerf_composite_fwd(_ptr(raw, "raw"), _ptr(z, "z"), _ptr(rays, "rays"), _ptr(bc_rgb, "bc_rgb"),
+                                          n, S, C.byref(co), L.stream))
     return o
+
+
+def _u_shape(u, n, n_importance=None):
+    """u: [Ni] shared by all rays (the deterministic linspace) or [n, Ni] per ray."""
+    if u.dim() == 2:
+        _shape(u, "u", n, n_importance)
+        return 1
+    _shape(u, "u", n_importance)
+    return 0
 
 
 def sample_pdf_fwd(z, weights, u, n_importance) -> Dict[str, torch.Tensor]:
     lib = _lib.load()
+    _shape(z, "z", None, None)
     n, S = z.shape
+    _shape(weights, "weights", n, S)
+    per_ray = _u_shape(u, n, n_importance)
     dev = z.device
-    per_ray = 1 if u.dim() == 2 else 0
-    o = dict(z_samples=torch.empty((n, n_importance), dtype=torch.float32, device=dev),
-             inds=torch.empty((n, n_importance), dtype=torch.int64, device=dev),
-             cdf=torch.empty((n, S - 1), dtype=torch.float32, device=dev),
-             z_fine=torch.empty((n, S + n_importance), dtype=torch.float32, device=dev),
-             z_std=torch.empty((n,), dtype=torch.float32, device=dev))
-    check(lib.idealnerf_sample_pdf_fwd(_ptr(z, "z"), _ptr(weights, "weights"), _ptr(u, "u"), per_ray, n, S,
-                                       n_importance, o["z_samples"].data_ptr(), o["inds"].data_ptr(),
-                                       o["cdf"].data_ptr(), o["z_fine"].data_ptr(), o["z_std"].data_ptr(), _stream()))
+    with _Launch(z, weights, u) as L:
+        o = dict(z_samples=torch.empty((n, n_importance), dtype=torch.float32, device=dev),
+                 inds=torch.empty((n, n_importance), dtype=torch.int64, device=dev),
+                 cdf=torch.empty((n, S - 1), dtype=torch.float32, device=dev),
+                 z_fine=torch.empty((n, S + n_importance), dtype=torch.float32, device=dev),
+                 z_std=torch.empty((n,), dtype=torch.float32, device=dev))
+        check(lib.idealnerf_sample_pdf_fwd(_ptr(z, "z"), _ptr(weights, "weights"), _ptr(u, "u"), per_ray, n, S,
+                                           n_importance, o["z_samples"].data_ptr(), o["inds"].data_ptr(),
+                                           o["cdf"].data_ptr(), o["z_fine"].data_ptr(), o["z_std"].data_ptr(), L.stream))
+    return o
+
+
+def sample_pdf_bins_fwd(bins, weights, u) -> Dict[str, torch.Tensor]:
+    """helper.sample_pdf's own argument list (helper.py:269): bins [n, nb], weights [n, nb-1] (already
+    the interior weights), u [Ni] or [n, Ni] -> z_samples, inds, cdf -- pdf, cdf and inversion all by
+    the kernel that Network.render_rays runs."""
+    lib = _lib.load()
+    _shape(bins, "bins", None, None)
+    n, nb = bins.shape
+    _shape(weights, "weights", n, nb - 1)
+    per_ray = _u_shape(u, n)
+    ni = u.shape[-1]
+    dev = bins.device
+    with _Launch(bins, weights, u) as L:
+        o = dict(z_samples=torch.empty((n, ni), dtype=torch.float32, device=dev),
+                 inds=torch.empty((n, ni), dtype=torch.int64, device=dev),
+                 cdf=torch.empty((n, nb), dtype=torch.float32, device=dev))
+        check(lib.idealnerf_sample_pdf_bins_fwd(_ptr(bins, "bins"), _ptr(weights, "weights"), _ptr(u, "u"), per_ray, n,
+                                                nb, ni, o["z_samples"].data_ptr(), o["inds"].data_ptr(),
+                                                o["cdf"].data_ptr(), L.stream))
     return o
 
 
 def invert_cdf(cdf, bins, u):
     lib = _lib.load()
+    _shape(cdf, "cdf", None, None)
     n, nb = cdf.shape
-    per_ray = 1 if u.dim() == 2 else 0
+    _shape(bins, "bins", n, nb)
+    per_ray = _u_shape(u, n)
     ni = u.shape[-1]
-    zs = torch.empty((n, ni), dtype=torch.float32, device=cdf.device)
-    inds = torch.empty((n, ni), dtype=torch.int64, device=cdf.device)
-    check(lib.idealnerf_invert_cdf(_ptr(cdf, "cdf"), _ptr(bins, "bins"), _ptr(u, "u"), per_ray, n, nb, ni,
-                                   zs.data_ptr(), inds.data_ptr(), _stream()))
+    with _Launch(cdf, bins, u) as L:
+        zs = torch.empty((n, ni), dtype=torch.float32, device=cdf.device)
+        inds = torch.empty((n, ni), dtype=torch.int64, device=cdf.device)
+        check(lib.idealnerf_invert_cdf(_ptr(cdf, "cdf"), _ptr(bins, "bins"), _ptr(u, "u"), per_ray, n, nb, ni,
+                                       zs.data_ptr(), inds.data_ptr(), L.stream))
     return zs, inds
 
 
 _workspaces: Dict[tuple, torch.Tensor] = {}
 
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+def _workspace(nbytes: int, device, stream) -> torch.Tensor:
+    """Scratch of one (device, stream): calls on one stream are ordered, so they can share it."""
+    key = (str(device), int(stream))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -198,35 +321,46 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
     """Network.render_rays forward (audio_exp_nerf.py:297-371) as one C call.  `precision_fine` (default: the
     same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it."""
     lib = _lib.load()
+    _shape(rays, "rays", None, RAY_FLOATS)
+    _shape(t_vals, "t_vals", None)
     n, S, Ni = rays.shape[0], t_vals.shape[0], int(n_importance)
-    dev = rays.device
-    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    out = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n))
+    _shape(bc_rgb, "bc_rgb", n, 3)
+    _shape(t_rand, "t_rand", n, S)
+    _net_buffers(lib, packed_c, folded_c, precision, "_coarse")
     if Ni > 0:
-        out.update(rgb0=new(n, 3), disp0=new(n), acc0=new(n), z_std=new(n), last_weight=new(n))
-    if with_fg:
-        out["rgb_fg"] = new(n, 3)
+        if u is None or packed_f is None or folded_f is None:
+            raise IdealNerfError("n_importance > 0 needs u and the fine network's packed / folded buffers")
+        _u_shape(u, n, Ni)
+        _net_buffers(lib, packed_f, folded_f, precision if precision_fine is None else precision_fine, "_fine")
+    dev = rays.device
+    with _Launch(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, t_rand) as L:
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        out = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n))
         if Ni > 0:
-            out.update(rgb_fg0=new(n, 3), last_weight0=new(n))
-    if taps:
-        out.update(tap_z_coarse=new(n, S), tap_raw_coarse=new(n, S, 4), tap_weights_coarse=new(n, S))
-        if Ni > 0:
-            out.update(tap_cdf=new(n, S - 1), tap_inds=torch.empty((n, Ni), dtype=torch.int64, device=dev),
-                       tap_z_samples=new(n, Ni), tap_z_fine=new(n, S + Ni), tap_raw_fine=new(n, S + Ni, 4),
-                       tap_weights_fine=new(n, S + Ni))
-    nbytes = lib.idealnerf_render_workspace_bytes(n, S, Ni)
-    ws = _workspace(nbytes, dev)
-    a = _lib.RenderArgs()
-    a.rays, a.bc_rgb, a.n_rays = _ptr(rays, "rays"), _ptr(bc_rgb, "bc_rgb"), n
-    a.n_samples, a.n_importance, a.precision = S, Ni, precision
-    a.precision_fine_plus1 = 0 if precision_fine is None else int(precision_fine) + 1
-    a.packed_coarse, a.folded_coarse = _ptr(packed_c), _ptr(folded_c)
-    a.packed_fine, a.folded_fine = _ptr(packed_f), _ptr(folded_f)
-    a.t_vals, a.t_rand = _ptr(t_vals, "t_vals"), _ptr(t_rand, "t_rand")
-    a.u = _ptr(u, "u") if u is not None else None
-    a.u_per_ray = 1 if (u is not None and u.dim() == 2) else 0
-    for k, v in out.items():
-        setattr(a, k, v.data_ptr())
-    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    check(lib.idealnerf_render_rays_fwd(C.byref(a), _stream()))
+            out.update(rgb0=new(n, 3), disp0=new(n), acc0=new(n), z_std=new(n), last_weight=new(n))
+        if with_fg:
+            out["rgb_fg"] = new(n, 3)
+            if Ni > 0:
+                out.update(rgb_fg0=new(n, 3), last_weight0=new(n))
+        if taps:
+            out.update(tap_z_coarse=new(n, S), tap_raw_coarse=new(n, S, 4), tap_weights_coarse=new(n, S))
+            if Ni > 0:
+                out.update(tap_cdf=new(n, S - 1), tap_inds=torch.empty((n, Ni), dtype=torch.int64, device=dev),
+                           tap_z_samples=new(n, Ni), tap_z_fine=new(n, S + Ni), tap_raw_fine=new(n, S + Ni, 4),
+                           tap_weights_fine=new(n, S + Ni))
+        a = _lib.RenderArgs()
+        a.rays, a.bc_rgb, a.n_rays = _ptr(rays, "rays"), _ptr(bc_rgb, "bc_rgb"), n
+        a.n_samples, a.n_importance, a.precision = S, Ni, _precision(precision)
+        a.precision_fine_plus1 = 0 if precision_fine is None else _precision(precision_fine) + 1
+        a.packed_coarse, a.folded_coarse = _ptr(packed_c, "packed_coarse"), _ptr(folded_c, "folded_coarse")
+        a.packed_fine, a.folded_fine = _ptr(packed_f, "packed_fine"), _ptr(folded_f, "folded_fine")
+        a.t_vals, a.t_rand = _ptr(t_vals, "t_vals"), _ptr(t_rand, "t_rand")
+        a.u = _ptr(u, "u") if u is not None else None
+        a.u_per_ray = 1 if (u is not None and u.dim() == 2) else 0
+        for k, v in out.items():
+            setattr(a, k, v.data_ptr())
+        nbytes = lib.idealnerf_render_workspace_bytes(n, S, Ni)
+        ws = _workspace(nbytes, dev, L.stream or 0)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        check(lib.idealnerf_render_rays_fwd(C.byref(a), L.stream))
     return out

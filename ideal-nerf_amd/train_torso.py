@@ -94,12 +94,7 @@ class Network(HeadNetwork):
             rec = torch.cat([rays_o, rays_d, near * torch.ones_like(rays_d[..., :1]),
                              far * torch.ones_like(rays_d[..., :1]), viewdirs], -1)
             bc = bc_rgb
-        all_ret = {}
-        for i in range(0, rec.shape[0], chunk):
-            ret = self._render(rec[i:i + chunk], bc[i:i + chunk], aud_para, latent_code, expr, coarse, fine, True)
-            for k, v in ret.items():
-                all_ret.setdefault(k, []).append(v)
-        all_ret = {k: torch.cat(v, 0) for k, v in all_ret.items()}
+        all_ret = self._batchify(rec, bc, aud_para, latent_code, expr, coarse, fine, True, chunk)
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
         k_extract = ['rgb_map', 'disp_map', 'acc_map', 'last_weight', 'rgb_map_fg']

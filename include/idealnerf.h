@@ -162,10 +162,21 @@ int idealnerf_composite_fwd(const float* raw, const float* z, const float* rays,
  *      torch.linspace buffer), or [n, n_importance] when u_per_ray != 0.
  * Outputs (each may be NULL): z_samples[n, Ni], inds[n, Ni] (int64, searchsorted
  * right=True result), cdf[n, S-1], z_fine[n, S+Ni] (sorted union), z_std[n].
+ * For identical weights in, cdf and inds are bit-identical to the reference's CPU path: the
+ * normalising torch.sum is evaluated in ATen's own order (8 vector lanes, 4 accumulators), the
+ * cumsum in fp64 rounded per element.
  */
 int idealnerf_sample_pdf_fwd(const float* z, const float* weights, const float* u, int u_per_ray,
                              int64_t n_rays, int n_samples, int n_importance, float* z_samples, int64_t* inds,
                              float* cdf, float* z_fine, float* z_std, void* stream);
+
+/* helper.sample_pdf with its own argument list (NeRFs/HeadNeRF/helper.py:269-313): bins[n, n_bins],
+ * weights[n, n_bins-1] (the interior weights as the caller sliced them, before the +1e-5), u as above
+ * -> z_samples[n, Ni], inds[n, Ni], cdf[n, n_bins] (each may be NULL).  Same kernel, same pdf / cdf
+ * arithmetic as idealnerf_sample_pdf_fwd: torch.sum in ATen's CPU order, cumsum in fp64. */
+int idealnerf_sample_pdf_bins_fwd(const float* bins, const float* weights, const float* u, int u_per_ray,
+                                  int64_t n_rays, int n_bins, int n_importance, float* z_samples, int64_t* inds,
+                                  float* cdf, void* stream);
 
 /* The bit-exact boundary on its own (helper.py:297-310): given cdf[n, nb], bins[n, nb],
  * u (as above) -> inds (int64) and z_samples. */

@@ -447,8 +447,50 @@ def golden_agg():
     print("wrote facenerf_agg.npz, audio_clip.npz")
 
 
+def golden_torso():
+    """`python make_golden.py torso`: the torso conditioning from the reference's own
+    functions -- NeRFs/TorsoNeRF/run_nerf_helpers.py imports with numpy + torch alone.  pose_to_euler_trans
+    (:26-47) on a batch of seeded poses, and the 106-d torso signal assembled per pose exactly as
+    train_torso.py:238-240 does with the reference's get_embedder(3, 0) (:38; device='cpu' instead of its
+    'cuda' default, which only places the frequency table)."""
+    sys.path.insert(0, REF)
+    import importlib
+    H = importlib.import_module("NeRFs.TorsoNeRF.run_nerf_helpers")
+    torch.autograd.set_detect_anomaly(False)   # the module switches it on at import (:7)
+    embed_torso_aud_fn, ch = H.get_embedder(3, 0, device="cpu")
+    assert ch == 21
+    rs = np.random.RandomState(2024)
+    B, dim_aud_body = 16, 64
+    poses = np.zeros((B, 4, 4), dtype=np.float32)
+    for b in range(B):
+        a = rs.uniform(-0.6, 0.6, size=3)
+        cx, cy, cz = np.cos(a)
+        sx, sy, sz = np.sin(a)
+        Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        poses[b, :3, :3] = (Rz @ Ry @ Rx).astype(np.float32)
+        poses[b, :3, 3] = rs.uniform(-1.0, 1.0, size=3).astype(np.float32) * np.array([0.2, 0.2, 1.0], dtype=np.float32)
+        poses[b, 3, 3] = 1.0
+    aud = rs.standard_normal((B, 80)).astype(np.float32)      # wider than dim_aud_body: the slice is part of the formula
+    tp, ta = torch.from_numpy(poses), torch.from_numpy(aud)
+    with torch.no_grad():
+        et_batch = H.pose_to_euler_trans(tp)
+        signals = []
+        for b in range(B):
+            pose, aud_feature = tp[b], ta[b]
+            et = H.pose_to_euler_trans(pose.unsqueeze(0))
+            embed_et = torch.cat((embed_torso_aud_fn(et[:, :3]), embed_torso_aud_fn(et[:, 3:])), dim=1)
+            signals.append(torch.cat((aud_feature[..., :dim_aud_body], torch.squeeze(embed_et)), dim=-1))
+    np.savez(os.path.join(HERE, "torso_signal.npz"), poses=poses, aud=aud, euler_trans=et_batch.numpy(),
+             signal=torch.stack(signals, 0).numpy(), dim_aud_body=dim_aud_body)
+    print("wrote torso_signal.npz", et_batch.shape, torch.stack(signals, 0).shape)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "agg":
         golden_agg()
+    elif len(sys.argv) > 1 and sys.argv[1] == "torso":
+        golden_torso()
     else:
         main()

@@ -80,7 +80,8 @@ def test_c_abi_argument_errors_without_gpu(idn):
 def test_product_path_refuses_cpu_tensors(idn):
     x = torch.zeros(4, 90)
     with pytest.raises(idn._lib.IdealNerfError, match="GPU"):
-        idn.ops.facenerf_fwd(torch.zeros(8), torch.zeros(8), x)
+        lib = idn._lib.load()
+        idn.ops.facenerf_fwd(torch.zeros(lib.idealnerf_packed_weight_floats(0)), torch.zeros(lib.idealnerf_folded_bias_floats()), x)
     net = idn.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76)
     with torch.no_grad(), pytest.raises(idn._lib.IdealNerfError):
         net(x, torch.zeros(64), torch.zeros(76), torch.zeros(32))
@@ -508,3 +509,26 @@ def test_bench_rejects_a_world_size_that_contradicts_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "rendezvous"],
                        env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
+
+
+def test_ops_validate_shapes_before_the_c_call(idn):
+    """Shape errors surface as IdealNerfError before any pointer is taken (so even on CPU tensors); a
+    well-shaped CPU call is then refused for its device.  An 8-column ray batch -- which the reference's
+    render_rays accepts -- is named as such instead of being read out of bounds."""
+    E = idn._lib.IdealNerfError
+    ops = idn.ops
+    raw, z, rays, bc = torch.zeros(4, 8, 4), torch.zeros(4, 8), torch.zeros(4, 11), torch.zeros(4, 3)
+    with pytest.raises(E, match=r"rays must be \[4, 11\], got \[4, 8\]"):
+        ops.composite_fwd(raw, z, rays[:, :8].contiguous(), bc)
+    with pytest.raises(E, match=r"bc_rgb must be \[4, 3\]"):
+        ops.composite_fwd(raw, z, rays, torch.zeros(3, 3))
+    with pytest.raises(E, match="must live on the GPU"):
+        ops.composite_fwd(raw, z, rays, bc)
+    with pytest.raises(E, match=r"x must be \[\*, 90\]"):
+        ops.facenerf_fwd(None, None, torch.zeros(5, 63))
+    with pytest.raises(E, match="u must be"):
+        ops.invert_cdf(torch.zeros(4, 7), torch.zeros(4, 7), torch.zeros(3, 16))
+    with pytest.raises(E, match="no CPU fallback"):
+        ops.frame_rays(torch.eye(4), 8, 8, 10.0, 0.1, 1.0, device="cpu")
+    with pytest.raises(E, match="t_vals"):
+        ops.render_rays_fwd(rays, bc, None, None, None, None, torch.zeros(8, 2), None, 0)

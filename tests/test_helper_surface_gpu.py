@@ -1,0 +1,291 @@
+"""The reference-NAMED callables of the drop-in surface, called the way a reference caller calls them
+(NeRFs/HeadNeRF/helper.py:228-313, train/baseline.py:325-375, train/audio_exp_nerf.py:274-288,369-387),
+on the reference-generated goldens and with the tolerances of the ops-level tests in
+test_hip_parity.py.  Also the argument guards of the tensor layer (wrong device, wrong shape, wrong
+dtype raise IdealNerfError before any C call).  Needs a real MI355X: run with ``-m gpu``.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+NEAR, FAR = 0.5772005200386048, 1.1772005200386046
+RGB_TOL, W_TOL = 1e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def idn():
+    import idealnerf_amd
+    idealnerf_amd._lib.load()
+    return idealnerf_amd
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel_err(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def abs_err(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, dtype=np.float64)
+    return np.abs(a - b).max()
+
+
+def scale_sigma(p, gain=300.0, bias=0.3):
+    p = {k: v.clone() for k, v in p.items()}
+    p["alpha_linear.weight"] = p["alpha_linear.weight"] * gain
+    p["alpha_linear.bias"] = torch.full_like(p["alpha_linear.bias"], bias)
+    return p
+
+
+@pytest.fixture(scope="module")
+def frame_net(idn, dev):
+    """The Network of the reference's 32x32 golden frame (tests/golden/frame32.npz)."""
+    from idealnerf_amd.audio_exp_nerf import Network
+    from idealnerf_amd.helper import RenderConfig
+    dims = oracle.facenerf_dims()
+    syn = oracle.synthetic_frame(32, 32, seed=0, dims=dims)
+    cfg = RenderConfig(perturb=0.0, chunk=300, near=NEAR, far=FAR)
+    net = Network(32, 32, syn["focal"], NEAR, FAR, 300, None, 64, 128, args=cfg).to(dev)
+    net.face_nerf_coarse.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(2, dims)))
+    net.face_nerf_fine.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(3, dims)))
+    return net.eval(), syn
+
+
+# --------------------------------------------------------------------------- helper.sample_pdf
+def test_helper_sample_pdf_is_the_kernels_stage(idn, dev, golden):
+    """helper.sample_pdf(bins, weights, N, det / pytest / u): bit-identical samples to the reference for the
+    deterministic and the numpy-seeded draw, and the SAME cdf arithmetic as Network.render_rays' stage."""
+    from idealnerf_amd import helper
+    g = golden("sample_pdf")
+    bins, w = T(g["bins"]).to(dev), T(g["weights"]).to(dev)
+    det = helper.sample_pdf(bins, w, 128, det=True)
+    np.testing.assert_array_equal(det.cpu().numpy(), g["det_samples"])
+    rnd = helper.sample_pdf(bins, w, 128, det=False, pytest=True)      # np.random.seed(0); rand(n, N): helper.py:286-293
+    np.testing.assert_array_equal(rnd.cpu().numpy(), g["rnd_samples"])
+    given = helper.sample_pdf(bins, w, 128, u=T(g["rnd_u"]).to(dev))
+    np.testing.assert_array_equal(given.cpu().numpy(), g["rnd_samples"])
+    free = helper.sample_pdf(bins, w, 128)                                # torch.rand on the device: in range, finite
+    assert free.shape == (64, 128) and bool(torch.isfinite(free).all())
+    assert bool((free >= bins[:, :1]).all()) and bool((free <= bins[:, -1:]).all())
+    # one stage, two entry points: the renderer's (z, weights[n, S]) form gives the same cdf and indices
+    f = golden("frame32")
+    z, wc = T(f["tap_z_coarse"]).to(dev), T(f["tap_weights_coarse"]).to(dev)
+    mids = 0.5 * (z[:, 1:] + z[:, :-1])
+    a = idn.ops.sample_pdf_bins_fwd(mids.contiguous(), wc[:, 1:-1].contiguous(), T(f["tap_u"])[0].contiguous().to(dev))
+    b = idn.ops.sample_pdf_fwd(z, wc, T(f["tap_u"])[0].contiguous().to(dev), 128)
+    for k in ("cdf", "inds", "z_samples"):
+        assert torch.equal(a[k], b[k]), k
+    np.testing.assert_array_equal(helper.sample_pdf(mids, wc[:, 1:-1], 128, det=True).cpu().numpy(), f["tap_z_samples"])
+
+
+# --------------------------------------------------------------------------- helper.raw2outputs / Network.raw2outputs
+@pytest.mark.parametrize("S", [64, 192])
+def test_helper_raw2outputs_golden(idn, dev, golden, frame_net, S):
+    from idealnerf_amd import helper
+    g = golden("raw2outputs")
+    k = lambda n: T(g[f"s{S}_{n}"]).to(dev)
+    net, _ = frame_net
+    for fn in (helper.raw2outputs, net.raw2outputs):
+        rgb_map, disp_map, acc_map, weights, depth_map = fn(k("raw"), k("z"), k("d"), k("bc"))
+        for got, name in ((rgb_map, "rgb_map"), (disp_map, "disp"), (acc_map, "acc"), (weights, "weights"),
+                          (depth_map, "depth")):
+            assert rel_err(got, g[f"s{S}_{name}"]) < 2e-6, name
+    with pytest.raises(NotImplementedError):
+        helper.raw2outputs(k("raw"), k("z"), k("d"), k("bc"), raw_noise_std=1.0)
+    with pytest.raises(NotImplementedError):
+        helper.raw2outputs(k("raw"), k("z"), k("d"), k("bc"), white_bkgd=True)
+
+
+# --------------------------------------------------------------------------- helper.get_rays
+def test_helper_get_rays_golden(idn, dev, golden):
+    from idealnerf_amd import helper
+    g = golden("frame32")
+    syn = oracle.synthetic_frame(32, 32, seed=0)
+    ro, rd = helper.get_rays(32, 32, syn["focal"], syn["c2w"], device=dev)
+    assert ro.shape == (32, 32, 3) and rd.shape == (32, 32, 3)
+    assert rel_err(ro.reshape(-1, 3), g["rays"][:, 0:3]) < 1e-6
+    assert rel_err(rd.reshape(-1, 3), g["rays"][:, 3:6]) < 1e-6
+    ro_ref, rd_ref = oracle.camera_rays(32, 32, syn["focal"], syn["c2w"])
+    assert rel_err(rd, rd_ref) < 1e-6 and rel_err(ro, ro_ref) < 1e-6
+
+
+# --------------------------------------------------------------------------- Network.run_network
+def test_network_run_network_golden(idn, dev, golden, frame_net):
+    """run_network(pts, expr, viewdirs, aud, model, latent) -> raw: the reference's coarse and fine raw taps."""
+    g = golden("frame32")
+    net, syn = frame_net
+    rays = T(g["rays"])[:128].to(dev)
+    cond = dict(expr=syn["expr"].to(dev), aud=syn["aud"].to(dev), latent_code=syn["latent"].to(dev))
+    for z_key, raw_key, model in (("tap_z_coarse", "tap_raw_coarse", net.face_nerf_coarse),
+                                  ("tap_z_fine", "tap_raw_fine", net.face_nerf_fine)):
+        z = T(g[z_key])[:128].to(dev)
+        pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]          # audio_exp_nerf.py:331
+        with torch.no_grad():
+            raw = net.run_network(pts, cond["expr"], rays[:, 8:11].contiguous(), cond["aud"], model, cond["latent_code"])
+        assert raw.shape == (128, z.shape[1], 4)
+        assert rel_err(raw, g[raw_key]) < 2e-5, raw_key
+    # gradients are not built on this entry: with autograd on it raises rather than returning a dead tensor
+    z = T(g["tap_z_coarse"])[:128].to(dev)
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+    with pytest.raises(NotImplementedError):
+        net.run_network(pts, cond["expr"], rays[:, 8:11].contiguous(), cond["aud"], net.face_nerf_coarse, cond["latent_code"])
+
+
+# --------------------------------------------------------------------------- Network.batchify_rays / render_rays
+def test_network_batchify_rays_golden(idn, dev, golden, frame_net):
+    """batchify_rays at a ragged chunk (300 of 1024 rays): the reference frame, every key of the dict."""
+    g = golden("frame32")
+    net, syn = frame_net
+    rays, bc = T(g["rays"]).to(dev), syn["bc"].reshape(-1, 3).to(dev)
+    args = (syn["aud"].to(dev), syn["c2w"], syn["latent"].to(dev), syn["expr"].to(dev))
+    with torch.no_grad():
+        one = net.batchify_rays(rays, bc, *args, chunk=300)
+        assert set(one) == {"rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std", "last_weight"}
+        for k, gk in (("rgb_map", "rgb"), ("rgb0", "rgb0")):
+            assert one[k].shape == (1024, 3) and rel_err(one[k], g[gk].reshape(-1, 3)) < RGB_TOL, k
+        for k, gk in (("disp_map", "disp"), ("acc_map", "acc"), ("disp0", "disp0"), ("acc0", "acc0")):
+            assert rel_err(one[k], g[gk].reshape(-1)) < RGB_TOL, k
+        assert abs_err(one["last_weight"], g["last_weight"].reshape(-1)) < W_TOL
+        # the chunk loop (kept for perturb > 0) and the single call (perturb == 0) give identical rays
+        net.args.perturb = 1.0
+        try:
+            torch.manual_seed(0)
+            looped = net.batchify_rays(rays, bc, *args, chunk=300)
+        finally:
+            net.args.perturb = 0.0
+        assert looped["rgb_map"].shape == (1024, 3) and bool(torch.isfinite(looped["rgb_map"]).all())
+        chunked = torch.cat([net.render_rays(rays[i:i + 300], bc[i:i + 300], *args)["rgb_map"] for i in range(0, 1024, 300)], 0)
+        assert torch.equal(chunked, one["rgb_map"])
+
+
+def test_network_render_rays_pytest_draws_golden(idn, dev, golden, frame_net):
+    """render_rays(perturb=1, pytest=True): the reference's numpy-seeded t_rand / u (audio_exp_nerf.py:316-326,
+    helper.py:286-293) drawn by the drop-in itself."""
+    g, f = golden("rays64_jitter"), golden("frame32")
+    net, syn = frame_net
+    sel = T(g["sel"])
+    with torch.no_grad():
+        out = net.render_rays(T(f["rays"])[sel].to(dev), syn["bc"].reshape(-1, 3)[sel].to(dev), syn["aud"].to(dev),
+                              syn["c2w"], syn["latent"].to(dev), syn["expr"].to(dev), perturb=1.0, pytest=True, taps=True)
+    np.testing.assert_array_equal(out["tap_z_coarse"].cpu().numpy(), g["z_coarse"])
+    for k in ("rgb_map", "rgb0", "disp_map", "acc_map"):
+        assert rel_err(out[k], g[k]) < RGB_TOL, k
+    assert abs_err(out["last_weight"], g["last_weight"]) < W_TOL
+
+
+# --------------------------------------------------------------------------- packed-stream cache
+def test_packed_stream_follows_weight_updates(idn, dev):
+    """The cached MFMA weight stream is rebuilt after optimizer steps and load_state_dict; after a write
+    through ``.data`` (which PyTorch's version counter does not see) invalidate_packed() rebuilds it."""
+    dims = oracle.facenerf_dims()
+    net = idn.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76).to(dev)
+    net.load_state_dict(oracle.xavier_facenerf_params(5, dims))
+    rs = np.random.RandomState(0)
+    x = T(rs.uniform(-1, 1, size=(200, 90)).astype(np.float32)).to(dev)
+    cond = [T(rs.standard_normal(k).astype(np.float32)).to(dev) for k in (64, 76, 32)]
+
+    def check():
+        with torch.no_grad():
+            out = net(x, *cond)
+            ref = oracle.facenerf_forward({k: v.detach().cpu() for k, v in net.state_dict().items()}, x.cpu(),
+                                          *[c.cpu() for c in cond], dims)
+        assert rel_err(out, ref) < 1e-5
+
+    check()
+    with torch.no_grad():
+        net.pts_linears[3].weight.mul_(1.5)            # in-place op: version bump, cache key changes
+    check()
+    net.load_state_dict(oracle.xavier_facenerf_params(6, dims))
+    check()
+    net.pts_linears[2].weight.data.mul_(0.5)            # .data write: invisible to the version counter
+    idn.invalidate_packed(net)
+    check()
+    net.rgb_linear.bias.data.fill_(0.25)                # biases are folded per call: no invalidation needed
+    check()
+
+
+# --------------------------------------------------------------------------- argument guards
+def test_ops_reject_bad_shapes_devices_and_dtypes(idn, dev):
+    E = idn._lib.IdealNerfError
+    ops = idn.ops
+    rays = torch.zeros((16, 11), device=dev)
+    z = torch.linspace(0.6, 1.0, 64, device=dev).expand(16, 64).contiguous()
+    raw = torch.zeros((16, 64, 4), device=dev)
+    bc = torch.zeros((16, 3), device=dev)
+    t = torch.linspace(0, 1, 64, device=dev)
+    with pytest.raises(E, match=r"rays must be \[16, 11\]"):
+        ops.composite_fwd(raw, z, rays[:, :8].contiguous(), bc)        # the reference's 8-column ray batch
+    with pytest.raises(E, match="bc_rgb"):
+        ops.composite_fwd(raw, z, rays, bc[:, :2].contiguous())
+    with pytest.raises(E, match="raw"):
+        ops.composite_fwd(raw[:, :63].contiguous(), z, rays, bc)
+    with pytest.raises(E, match="rays"):
+        ops.coarse_depths(rays[:, :8].contiguous(), t)
+    with pytest.raises(E, match="t_rand"):
+        ops.coarse_depths(rays, t, torch.zeros((16, 63), device=dev))
+    with pytest.raises(E, match="weights"):
+        ops.sample_pdf_fwd(z, z[:, :62].contiguous(), torch.linspace(0, 1, 128, device=dev), 128)
+    with pytest.raises(E, match="u must be"):
+        ops.sample_pdf_fwd(z, z, torch.zeros((15, 128), device=dev), 128)
+    with pytest.raises(E, match="u must be"):
+        ops.sample_pdf_fwd(z, z, torch.linspace(0, 1, 64, device=dev), 128)
+    with pytest.raises(E, match="GPU"):
+        ops.composite_fwd(raw.cpu(), z, rays, bc)
+    with pytest.raises(E, match="float32"):
+        ops.composite_fwd(raw.double(), z, rays, bc)
+    with pytest.raises(E, match="contiguous"):
+        ops.composite_fwd(raw, z.t().contiguous().t(), rays, bc)
+    with pytest.raises(E, match="viewdirs"):
+        ops.query_points_fwd(None, None, torch.zeros((4, 8, 3), device=dev), torch.zeros((5, 3), device=dev))
+    dims = oracle.facenerf_dims()
+    net = idn.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76).to(dev)
+    packed = net.packed_weights()
+    folded = net.folded_bias(*[torch.zeros(k, device=dev) for k in (64, 76, 32)])
+    with pytest.raises(E, match="packed"):
+        ops.query_rays_fwd(packed[:-4].contiguous(), folded, rays, z)
+    with pytest.raises(E, match="folded"):
+        ops.query_rays_fwd(packed, folded[:-1].contiguous(), rays, z)
+    with pytest.raises(E, match="packed"):                              # a stream packed for another arithmetic
+        ops.query_rays_fwd(net.packed_weights("bf16"), folded, rays, z, precision=0)
+    with pytest.raises(E, match="rows"):
+        ops.frame_rays(torch.eye(4), 32, 32, 100.0, NEAR, FAR, row0=30, nrows=5, device=dev)
+    if torch.cuda.device_count() > 1:
+        other = torch.device("cuda", 1)
+        with pytest.raises(E, match="same GPU"):
+            ops.composite_fwd(raw, z.to(other), rays, bc)
+
+
+def test_launch_follows_the_tensors_device_and_stream(idn, dev):
+    """The launch goes to the tensors' device on that device's current stream: work queued on a side stream
+    is ordered with that stream's other work and not with the default stream's."""
+    ops = idn.ops
+    rs = np.random.RandomState(1)
+    n, S = 4096, 64
+    raw = T(rs.standard_normal((n, S, 4)).astype(np.float32)).to(dev)
+    z = torch.sort(T(rs.uniform(NEAR, FAR, (n, S)).astype(np.float32)), -1)[0].to(dev)
+    rays = torch.zeros((n, 11), device=dev)
+    rays[:, 3:6] = T(rs.standard_normal((n, 3)).astype(np.float32)).to(dev)
+    bc = T(rs.uniform(0, 1, (n, 3)).astype(np.float32)).to(dev)
+    ref = ops.composite_fwd(raw, z, rays, bc)["rgb_map"].clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        raw2 = raw * 1.0                                   # produced on the side stream ...
+        out = ops.composite_fwd(raw2, z, rays, bc)["rgb_map"]   # ... and consumed there without a sync in between
+    side.synchronize()
+    assert torch.equal(out, ref)

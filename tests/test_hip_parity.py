@@ -53,9 +53,14 @@ def abs_err(a, b):
 # (CPU SLEEF vs GPU ocml differ in the last ulp of exp), and sample_pdf divides those
 # weights by a sum that can be as small as 62 * 1e-5: cdf noise up to ~1e-3 is inherent
 # to the reference's fp32 formula, not to this implementation.
+# At the sample_pdf STAGE (identical weights in) cdf and indices are bit-identical to the reference
+# (the kernel reproduces ATen's torch.sum order and the fp64 cumsum): those tests use array_equal.
+# END TO END the weights themselves differ in the last ulps, so the bounds below are ~3x what the
+# GPU runs measure (profiles/r02_pytest_gpu.log: fp32 flips 3.0e-4, max |cdf - ref| 4.7e-4).
 W_TOL = 1e-5
-CDF_TOL = 3e-3
-FLIP_TOL = 3e-2
+CDF_TOL = 1.5e-3
+FLIP_TOL = 1e-3
+FLIP_TOL_X3 = 3e-3   # bf16x3 / fp16x3 network outputs carry 1e-5 / 1e-6 instead of 1e-6
 
 
 def scale_sigma(p, gain=300.0, bias=0.3):
@@ -216,29 +221,107 @@ def test_invert_cdf_bit_exact(idn, dev, golden, mode):
     np.testing.assert_array_equal(zs.cpu().numpy(), g[mode + "_samples"])
 
 
+def _z_from_bins(bins):
+    """64 coarse depths whose midpoints are (to rounding) the golden bins: z0 free, z_{k+1} = 2 b_k - z_k."""
+    bins = bins.astype(np.float64)
+    z = np.empty((bins.shape[0], bins.shape[1] + 1), dtype=np.float64)
+    z[:, 0] = bins[:, 0] - 1e-3
+    for k in range(bins.shape[1]):
+        z[:, k + 1] = 2 * bins[:, k] - z[:, k]
+    return z.astype(np.float32)
+
+
 @pytest.mark.parametrize("mode", ["det", "rnd"])
 def test_sample_pdf_golden(idn, dev, golden, mode):
+    """The sample_pdf stage on the reference's captured inputs: identical weights in => cdf and
+    importance indices bit-identical out (north_star: "bit-exact on importance-sample indices")."""
     g = golden("sample_pdf")
-    # rebuild z (64 coarse depths) whose midpoints are the golden bins: z0 free, z_{k+1} = 2 b_k - z_k
-    bins = g["bins"].astype(np.float64)
-    z = np.empty((64, 64), dtype=np.float64)
-    z[:, 0] = bins[:, 0] - 1e-3
-    for k in range(63):
-        z[:, k + 1] = 2 * bins[:, k] - z[:, k]
-    z32 = z.astype(np.float32)
+    z32 = _z_from_bins(g["bins"])
     w = np.zeros((64, 64), dtype=np.float32)
     w[:, 1:-1] = g["weights"]
     u = T(g[mode + "_u"])
     u_dev = u[0].contiguous().to(dev) if mode == "det" else u.to(dev)
     o = idn.ops.sample_pdf_fwd(T(z32).to(dev), T(w).to(dev), u_dev, 128)
-    assert abs_err(o["cdf"], g[mode + "_cdf"]) < 1e-6   # identical weights in: only the sum's order differs
+    np.testing.assert_array_equal(o["cdf"].cpu().numpy(), g[mode + "_cdf"])
     flips = (o["inds"].cpu().numpy() != g[mode + "_inds"]).mean()
-    print(f"\nsample_pdf[{mode}]: index flip rate vs reference = {flips:.3e}")
-    assert flips < 5e-3, f"index flip rate {flips}"
+    print(f"\nsample_pdf[{mode}]: stage index flip rate vs reference = {flips:.3e} (cdf bit-identical)")
+    np.testing.assert_array_equal(o["inds"].cpu().numpy(), g[mode + "_inds"])
     # merged depths are exactly the sorted union of what the kernel itself produced
     ref_sorted = torch.sort(torch.cat([T(z32).to(dev), o["z_samples"]], -1), -1)[0]
     assert torch.equal(o["z_fine"], ref_sorted)
     assert rel_err(o["z_std"], torch.std(o["z_samples"], dim=-1, unbiased=False)) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["det", "rnd"])
+def test_sample_pdf_bins_entry_bit_exact(idn, dev, golden, mode):
+    """helper.sample_pdf's own argument list (bins, interior weights): cdf, indices AND samples bit-identical."""
+    g = golden("sample_pdf")
+    u = T(g[mode + "_u"])
+    u_dev = u[0].contiguous().to(dev) if mode == "det" else u.to(dev)
+    o = idn.ops.sample_pdf_bins_fwd(T(g["bins"]).to(dev), T(g["weights"]).to(dev), u_dev)
+    np.testing.assert_array_equal(o["cdf"].cpu().numpy(), g[mode + "_cdf"])
+    np.testing.assert_array_equal(o["inds"].cpu().numpy(), g[mode + "_inds"])
+    np.testing.assert_array_equal(o["z_samples"].cpu().numpy(), g[mode + "_samples"])
+
+
+def test_sample_pdf_stage_on_the_reference_frame_is_bit_exact(idn, dev, golden):
+    """All 1024 rays of the reference's 32x32 frame: its own coarse depths and coarse weights in =>
+    its cdf, indices, sampled depths and merged fine depths out, bit for bit."""
+    g = golden("frame32")
+    u = T(g["tap_u"])[0].contiguous().to(dev)
+    o = idn.ops.sample_pdf_fwd(T(g["tap_z_coarse"]).to(dev), T(g["tap_weights_coarse"]).to(dev), u, 128)
+    np.testing.assert_array_equal(o["cdf"].cpu().numpy(), g["tap_cdf"])
+    flips = (o["inds"].cpu().numpy() != g["tap_inds"].astype(np.int64)).mean()
+    print(f"\nframe32 sample_pdf stage (reference weights in): index flip rate = {flips:.3e}")
+    np.testing.assert_array_equal(o["inds"].cpu().numpy(), g["tap_inds"].astype(np.int64))
+    np.testing.assert_array_equal(o["z_samples"].cpu().numpy(), g["tap_z_samples"])
+    np.testing.assert_array_equal(o["z_fine"].cpu().numpy(), g["tap_z_fine"])
+    zs = T(g["tap_z_samples"])
+    assert rel_err(o["z_std"], torch.std(zs, dim=-1, unbiased=False)) < 1e-5
+
+
+@pytest.mark.parametrize("K", [1, 5, 7, 8, 9, 30, 31, 32, 33, 40, 62, 63, 64, 65, 126, 127, 200, 254])
+def test_sample_pdf_row_sum_follows_aten_order(idn, dev, K):
+    """torch.sum's CPU order for every row length the kernel takes (scalar tail only, one accumulator,
+    four accumulators, leftover vectors): the kernel's cdf equals the CPU formula bit for bit."""
+    rs = np.random.RandomState(K)
+    n, nb = 257, K + 1
+    bins = torch.sort(T(rs.uniform(NEAR, FAR, size=(n, nb)).astype(np.float32)), dim=-1)[0]
+    w = T((rs.uniform(0, 1, size=(n, K)) ** 8).astype(np.float32))
+    u = torch.linspace(0.0, 1.0, 64)
+    wp = w + 1e-5
+    pdf = wp / torch.sum(wp, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    zs_ref, inds_ref = oracle.invert_cdf(cdf, bins, u.expand(n, 64).contiguous())
+    o = idn.ops.sample_pdf_bins_fwd(bins.to(dev), w.to(dev), u.to(dev))
+    np.testing.assert_array_equal(o["cdf"].cpu().numpy(), cdf.numpy())
+    np.testing.assert_array_equal(o["inds"].cpu().numpy(), inds_ref.numpy())
+    np.testing.assert_array_equal(o["z_samples"].cpu().numpy(), zs_ref.numpy())
+
+
+def test_merge_handles_ties_unsorted_samples_and_nan(idn, dev):
+    """z_fine == torch.sort(cat[z, z_samples]) whatever branch merges: sorted halves with exact ties
+    (the binary-search merge), random u (unsorted samples: rank counting), and NaN depths (torch.sort
+    puts them last; every output slot is written)."""
+    rs = np.random.RandomState(4)
+    n = 300
+    z = torch.sort(T(rs.uniform(NEAR, FAR, size=(n, 64)).astype(np.float32)), dim=-1)[0]
+    z[::3, 10:20] = z[::3, 10:11]          # runs of equal coarse depths => zero-width bins, equal samples
+    w = T((rs.uniform(0, 1, size=(n, 64)) ** 6).astype(np.float32))
+    w[::5, 20:40] = 0.0
+    for u in (torch.linspace(0.0, 1.0, 128), T(rs.uniform(0, 1, size=(n, 128)).astype(np.float32))):
+        o = idn.ops.sample_pdf_fwd(z.to(dev), w.to(dev), u.to(dev), 128)
+        ref = torch.sort(torch.cat([z.to(dev), o["z_samples"]], -1), -1)[0]
+        assert torch.equal(o["z_fine"], ref)
+    zn = z.clone()
+    zn[7, 63] = float("nan")
+    zn[9, 5] = float("nan")               # a NaN in the middle: that half is no longer ordered
+    o = idn.ops.sample_pdf_fwd(zn.to(dev), w.to(dev), torch.linspace(0.0, 1.0, 128).to(dev), 128)
+    filled = torch.full_like(o["z_fine"], -1.0)
+    ref = torch.sort(torch.cat([zn.to(dev), o["z_samples"]], -1), -1)[0]
+    assert torch.equal(torch.isnan(o["z_fine"]), torch.isnan(ref))
+    ok = ~torch.isnan(ref)
+    assert torch.equal(o["z_fine"][ok], ref[ok]) and filled.shape == ref.shape
 
 
 def test_sample_pdf_own_cdf_is_bit_exact_boundary(idn, dev):
@@ -581,6 +664,23 @@ def test_head_torso_composite_matches_oracle(idn, dev):
     assert rel_err(rgb_com, ref) < RGB_TOL and rel_err(rgb_com0, ref0) < RGB_TOL
 
 
+def test_torso_signal_golden(idn, dev, golden):
+    """a11's conditioning against the reference's own pose_to_euler_trans (run_nerf_helpers.py:26-47) and
+    signal assembly (train_torso.py:238-240, get_embedder(3, 0)), computed on the GPU by the product module."""
+    from idealnerf_amd.helper import RenderConfig
+    from idealnerf_amd.train_torso import Network, pose_to_euler_trans
+    g = golden("torso_signal")
+    net = Network(8, 8, 100.0, NEAR, FAR, 64, None, 64, 128, args=RenderConfig(dim_expr=79)).to(dev)
+    poses, aud = T(g["poses"]).to(dev), T(g["aud"]).to(dev)
+    et = pose_to_euler_trans(poses)
+    assert abs_err(et, g["euler_trans"]) < 2e-6          # atan2 / asin: CPU SLEEF vs GPU ocml, last ulps
+    for b in range(poses.shape[0]):
+        sig = net.torso_signal(aud[b], poses[b])
+        assert sig.shape == (106,) and sig.device.type == "cuda"
+        np.testing.assert_array_equal(sig[:64].cpu().numpy(), g["signal"][b, :64])
+        assert abs_err(sig, g["signal"][b]) < 1e-5        # sin/cos of up to 4x the angle
+
+
 def test_head_torso_gradients_match_oracle(idn, dev):
     net, syn, P, dims, d = _torso_setup(idn, dev)
     net.train()
@@ -785,7 +885,7 @@ def test_bf16x3_render_frame32_golden(idn, dev, golden):
     print(f"\nbf16x3 frame32: rgb err {e_rgb:.2e}, rgb0 err {e_rgb0:.2e}, index flip rate {flips:.2e}, "
           f"PSNR vs reference {10 * np.log10(1.0 / max(mse, 1e-30)):.1f} dB")
     assert e_rgb < RGB_TOL and e_rgb0 < RGB_TOL
-    assert flips < FLIP_TOL
+    assert flips < FLIP_TOL_X3
     assert rel_err(out["tap_raw_coarse"][:128], g["tap_raw_coarse"]) < 1e-4
 
 
@@ -1070,6 +1170,16 @@ def test_head_torso_composite_bf16_modes_psnr(idn, dev):
           f"plain bf16 PSNR {p1:.1f} dB; coarse composite bf16x3 max {np.abs(outs['bf16x3'][1] - outs['f32'][1]).max():.1e}")
     assert p3 > 60.0 and p1 > 40.0
     assert rel_err(outs["bf16x3"][1], outs["f32"][1]) < RGB_TOL   # the coarse composite has no importance sampling before it
+    # the same three composites against the CPU oracle (pinned to the reference; torso conditioning pinned by
+    # tests/golden/torso_signal.npz), each at its mode's budget
+    (ref, ref0), _ = _torso_oracle(net, P, dims, d)
+    ref, ref0 = ref.numpy().astype(np.float64), ref0.numpy().astype(np.float64)
+    o3, o1 = psnr(outs["bf16x3"][0], ref), psnr(outs["bf16"][0], ref)
+    print(f"head+torso composite vs CPU oracle: fp32 max rel {rel_err(outs['f32'][0], ref):.1e}, bf16x3 PSNR {o3:.1f} dB, "
+          f"plain bf16 PSNR {o1:.1f} dB")
+    assert rel_err(outs["f32"][0], ref) < RGB_TOL and rel_err(outs["f32"][1], ref0) < RGB_TOL
+    assert o3 > 60.0 and o1 > 40.0
+    assert rel_err(outs["bf16x3"][1], ref0) < RGB_TOL
 
 
 def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golden):
@@ -1091,6 +1201,10 @@ def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golde
     print(f"\nmixed vs fp32 on the head+torso scene (512 rays): max rel err {e:.2e}")
     assert e < RGB_TOL
     np.testing.assert_array_equal(outs["mixed"][1], outs["f32"][1])   # the coarse composite is the same arithmetic
+    (ref, ref0), _ = _torso_oracle(net, P, dims, d)                    # and both against the CPU oracle
+    eo = rel_err(outs["mixed"][0], ref)
+    print(f"mixed vs CPU oracle on the head+torso scene: max rel err {eo:.2e} (fp32: {rel_err(outs['f32'][0], ref):.2e})")
+    assert eo < RGB_TOL and rel_err(outs["f32"][0], ref) < RGB_TOL and rel_err(outs["mixed"][1], ref0) < RGB_TOL
 
     g = golden("frame32")
     dims32 = oracle.facenerf_dims()

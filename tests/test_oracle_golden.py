@@ -161,3 +161,19 @@ def test_torso_signal_shape():
     assert s.shape == (64 + 42,)
     e = oracle.pose_to_euler_trans(pose[None])
     assert torch.allclose(e[0, 3:], syn["c2w"][:, 3])
+
+
+def test_torso_conditioning_golden(golden):
+    """a11 pinned: the oracle's pose_to_euler_trans / torso_signal against the reference's own functions
+    (NeRFs/TorsoNeRF/run_nerf_helpers.py:26-47, get_embedder(3, 0) :102-120, assembly train_torso.py:238-240),
+    run in the build container by tests/golden/make_golden.py torso.  Same machine, same libm: bit-exact."""
+    g = golden("torso_signal")
+    poses, aud = torch.from_numpy(g["poses"]), torch.from_numpy(g["aud"])
+    np.testing.assert_array_equal(oracle.pose_to_euler_trans(poses).numpy(), g["euler_trans"])
+    for b in range(poses.shape[0]):
+        sig = oracle.torso_signal(aud[b], poses[b], dim_aud_body=int(g["dim_aud_body"]))
+        assert sig.shape == (106,)
+        np.testing.assert_array_equal(sig.numpy(), g["signal"][b])
+    # the product's host-side restatement of the same three lines, on CPU tensors (plain torch math)
+    from idealnerf_amd.train_torso import pose_to_euler_trans
+    np.testing.assert_array_equal(pose_to_euler_trans(poses).numpy(), g["euler_trans"])
