@@ -56,11 +56,13 @@ def abs_err(a, b):
 # At the sample_pdf STAGE (identical weights in) cdf and indices are bit-identical to the reference
 # (the kernel reproduces ATen's torch.sum order and the fp64 cumsum): those tests use array_equal.
 # END TO END the weights themselves differ in the last ulps, so the bounds below are ~3x what the
-# GPU runs measure (profiles/r02_pytest_gpu.log: fp32 flips 3.0e-4, max |cdf - ref| 4.7e-4).
+# GPU runs measure (profiles/r02_pytest_gpu_first.log: fp32 4 flips of 131 072 = 3.1e-5, max |cdf - ref|
+# 7.9e-5; bf16x3 4.5e-4; fp16x3 6.1e-5.  Round 1, with an fp64 tree sum in place of ATen's order: 3.0e-4 / 4.7e-4).
 W_TOL = 1e-5
-CDF_TOL = 1.5e-3
-FLIP_TOL = 1e-3
-FLIP_TOL_X3 = 3e-3   # bf16x3 / fp16x3 network outputs carry 1e-5 / 1e-6 instead of 1e-6
+CDF_TOL = 3e-4
+Z_STD_TOL = 1.5e-3   # a statistic of the sampled depths
+FLIP_TOL = 2e-4
+FLIP_TOL_X3 = 1.5e-3   # the bf16x3 network output carries 1e-5 instead of 1e-6
 
 
 def scale_sigma(p, gain=300.0, bias=0.3):
@@ -371,7 +373,7 @@ def test_render_frame32_golden(idn, dev, golden):
         assert rel_err(out[k], g[gk].reshape(-1, 3)) < RGB_TOL, k
     for k, gk in (("disp_map", "disp"), ("acc_map", "acc"), ("disp0", "disp0"), ("acc0", "acc0")):
         assert rel_err(out[k], g[gk].reshape(-1)) < RGB_TOL, k
-    assert rel_err(out["z_std"], g["z_std"].reshape(-1)) < CDF_TOL  # a statistic of the sampled depths: follows the cdf
+    assert rel_err(out["z_std"], g["z_std"].reshape(-1)) < Z_STD_TOL
     assert abs_err(out["last_weight"], g["last_weight"].reshape(-1)) < W_TOL
     mse = float(((out["rgb_map"].cpu().numpy() - g["rgb"].reshape(-1, 3)) ** 2).mean())
     assert mse < 1e-10  # PSNR vs reference output > 100 dB
@@ -394,7 +396,7 @@ def test_render_rays_jitter_golden(idn, dev, golden):
     assert flips < FLIP_TOL
     for k in ("rgb_map", "rgb0", "disp_map", "acc_map"):
         assert rel_err(out[k], g[k]) < RGB_TOL, k
-    assert rel_err(out["z_std"], g["z_std"]) < CDF_TOL
+    assert rel_err(out["z_std"], g["z_std"]) < Z_STD_TOL
     assert abs_err(out["last_weight"], g["last_weight"]) < W_TOL
     # random u: the merge is a real sort; the result must be sorted and a permutation of the inputs
     zf = out["tap_z_fine"]
@@ -1231,7 +1233,7 @@ def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golde
                                   taps=True, precision=0, precision_fine=1)
     assert rel_err(out["rgb_map"], g["rgb"].reshape(-1, 3)) < RGB_TOL and rel_err(out["rgb0"], g["rgb0"].reshape(-1, 3)) < 1e-5
     flips = (out["tap_inds"].cpu().numpy() != g["tap_inds"].astype(np.int64)).mean()
-    assert flips < 1e-3   # the fp32 kernel's own flip rate, not bf16x3's
+    assert flips < FLIP_TOL   # the fp32 kernel's own flip rate, not bf16x3's
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
@@ -1314,7 +1316,7 @@ def test_fp16x3_render_frame32_golden(idn, dev, golden):
     flips = (out["tap_inds"].cpu().numpy() != g["tap_inds"].astype(np.int64)).mean()
     print(f"\nfp16x3 frame32: rgb err {e:.2e}, index flip rate {flips:.2e}")
     assert e < RGB_TOL and rel_err(out["rgb0"], g["rgb0"].reshape(-1, 3)) < 1e-5
-    assert flips < 2e-3
+    assert flips < 3e-4   # measured 6.1e-5 (8 of 131 072)
 
 
 def test_fp16x3_saturates_finitely_outside_fp16_range(idn, dev):
