@@ -1017,7 +1017,7 @@ def test_frame_sink_overlapped_copies(idn, dev, tmp_path):
     rs = np.random.RandomState(9)
     frames = [rs.uniform(-0.1, 1.1, size=(H * W, 3)).astype(np.float32) for _ in range(N)]
     frames[3][17, 2] = np.nan
-    sink = FrameSink(str(tmp_path / "clip.avi"), W, H, fps=25.0, device=dev, keep_frames=True)
+    sink = FrameSink(str(tmp_path / "clip.avi"), W, H, fps=25.0, device=dev, keep_frames=True, codec="raw")
     for f in frames:
         sink.submit(T(f).to(dev))
     sink.release()
@@ -1026,6 +1026,36 @@ def test_frame_sink_overlapped_copies(idn, dev, tmp_path):
         ref = (255 * np.clip(np.nan_to_num(f, nan=0.0), 0, 1)).astype(np.uint8).reshape(H, W, 3)
         np.testing.assert_array_equal(got, ref)
     assert (tmp_path / "clip.avi").stat().st_size > N * H * W * 3
+
+
+def test_frame_sink_mjpg_clip_and_stills(idn, dev, tmp_path):
+    """The reference's output (eval_aud_exp_nerf.py:482-496): an MJPG AVI at 25 fps plus a JPEG every 10th
+    frame.  Each '00dc' chunk, found through the idx1 index, decodes to the to8b frame within JPEG error."""
+    import io
+
+    from PIL import Image
+    from idealnerf_amd.frame_io import FrameSink, read_avi_chunks
+    H, W, N = 64, 80, 12
+    yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+    frames = [np.stack([0.5 + 0.5 * np.sin(6 * xx + 0.3 * i), yy, 0.5 + 0.5 * np.cos(5 * yy * xx + 0.2 * i)], -1)
+              .astype(np.float32).reshape(-1, 3) for i in range(N)]
+    sink = FrameSink(str(tmp_path / "clip.avi"), W, H, fps=25.0, device=dev, keep_frames=True,
+                     still_every=10, still_path=str(tmp_path / "still_{i}.jpg"))
+    for f in frames:
+        sink.submit(T(f).to(dev))
+    sink.release()
+    info, chunks = read_avi_chunks(str(tmp_path / "clip.avi"))
+    assert info["handler"] == b"MJPG" and info["compression"] == b"MJPG" and info["chunk_id"] == b"00dc"
+    assert (info["width"], info["height"], info["frames"]) == (W, H, N) and abs(info["fps"] - 25.0) < 1e-6
+    assert len(chunks) == N
+    for got8, chunk in zip(sink.frames, chunks):
+        assert chunk[:2] == b"\xff\xd8"                        # a JPEG per chunk
+        dec = np.asarray(Image.open(io.BytesIO(chunk)).convert("RGB"))[..., ::-1]   # back to the BGR order handed in
+        assert dec.shape == (H, W, 3)
+        assert np.abs(dec.astype(np.int32) - got8.astype(np.int32)).mean() < 2.0    # smooth content at quality 95
+    assert sorted(sink.stills) == [str(tmp_path / "still_0.jpg"), str(tmp_path / "still_10.jpg")]
+    still = np.asarray(Image.open(sink.stills[0]).convert("RGB"))[..., ::-1]
+    assert np.abs(still.astype(np.int32) - sink.frames[0].astype(np.int32)).mean() < 2.0
 
 
 def _agg_state(seed):
