@@ -26,6 +26,29 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE = 1_114_368      # algorithmic, SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2516.6   # dense bf16 MFMA: 16x the fp32 rate (1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
+# training step, per ray-sample: forward (as above) + dX (the transposed products of every layer that has a
+# hidden input: 7 x 256x256 + 256x129 + 2 x 128x128 + 128x3 MAC) + dW (every forward product once more)
+FLOP_PER_SAMPLE_DX = 2 * (7 * 65536 + 256 * 129 + 2 * 16384 + 384)     # 1 049 856
+FLOP_PER_SAMPLE_STEP = FLOP_PER_SAMPLE + FLOP_PER_SAMPLE_DX + FLOP_PER_SAMPLE   # 3 278 592 (SURVEY's 3x rounds up by 2 %)
+
+
+def mode_peaks():
+    # a bf16x3 kernel issues three bf16 MFMAs per algorithmic product: it is priced against peak / 3
+    # mixed = two kernels with two peaks (1/4 of the samples on the fp32 path, 3/4 on bf16x3): the blended
+    # peak is total FLOP / (coarse FLOP / fp32 peak + fine FLOP / (bf16 peak / 3)), so frac = ideal time / actual
+    mixed_peak = 1.0 / (0.25 / PEAK_F32_MFMA_TFLOPS + 0.75 / (PEAK_BF16_MFMA_TFLOPS / 3.0))
+    return {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3.0,
+            "bf16": PEAK_BF16_MFMA_TFLOPS, "mixed": mixed_peak}   # the dense fp16 and bf16 MFMA peaks are equal on gfx950
+
+
+def profile_kinds(lib):
+    """{kind: (ms, launches, points)} from the library's HIP-event profiler (idealnerf_profile_end_kinds)."""
+    import ctypes as C
+    import idealnerf_amd
+    n = len(idealnerf_amd._lib.PROF_KINDS)
+    ms, cnt, pts = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_int64 * n)()
+    lib.idealnerf_profile_end_kinds(ms, cnt, pts)
+    return {k: (ms[i], cnt[i], pts[i]) for i, k in enumerate(idealnerf_amd._lib.PROF_KINDS)}
 
 
 def launch_ranks(n, argv, script=None, timeout=None):
@@ -71,6 +94,51 @@ def launch_ranks(n, argv, script=None, timeout=None):
     return 0
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def kernel_source_sha16():
+    """Identity of the kernel sources a PMC summary belongs to (tools/pmc_summary.py stores the same hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "ideal-nerf_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(precision):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the process, so the
+    figure comes from the newest committed rocprofv3 --pmc summary of this same command for this arithmetic
+    (profiles/rNN_pmc_mlp_<prec>_final.json; tools/profile_round.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    separate passes) -- and only if that summary was taken from the kernel sources that are running now.
+    Returns (bytes or None, traffic_source dict)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_mlp_{precision}_final.json")))
+    if not files:
+        return None, {"file": None, "reason": "no PMC summary committed for this arithmetic"}
+    path = files[-1]
+    try:
+        pmc = json.load(open(path))
+        src = {"file": os.path.relpath(path, ROOT), "kernel_source_sha16": pmc.get("kernel_source_sha16"),
+               "commit": pmc.get("commit"), "current_kernel_source_sha16": kernel_source_sha16()}
+        if pmc.get("kernel_source_sha16") != src["current_kernel_source_sha16"]:
+            src["reason"] = "summary was taken from different kernel sources: not reported"
+            return None, src
+        return pmc["hbm_traffic_bytes_per_launch"], src
+    except (OSError, KeyError, ValueError) as e:
+        return None, {"file": os.path.relpath(path, ROOT), "reason": f"unreadable: {e}"}
+
+
 def host_cpu_share():
     """CPUs this process may actually use: the cgroup quota if there is one, else the
     affinity mask (the GPU box exposes 256 hardware threads but grants a 16-CPU share)."""
@@ -84,26 +152,33 @@ def host_cpu_share():
     return min(n, int(os.environ.get("IDN_CPU_THREADS", "16")))
 
 
-def cpu_baseline(syn, pc, pf, gpu_rgb_band, band_row0, n_rays=8192):
-    """The CPU oracle (a port of the reference's path, pinned to it by tests/golden) timed on
-    this host on a bounded sample: the first `n_rays` rays of the frame."""
+def cpu_baseline(syn, pc, pf, gpu_rgb_band, band_row0, n_rays=4096, runs=3):
+    """The CPU oracle (a port of the reference's path, pinned to it by tests/golden) timed on this host on a
+    bounded sample: the first `n_rays` rays of the frame, one warm-up on that same
+    tile, then the median of `runs` timed runs."""
+    import statistics
     import oracle
     W = syn["W"]
     nrows = (n_rays + W - 1) // W
     threads = host_cpu_share()
     torch.set_num_threads(threads)
     kw = dict(chunk=1024)
+    run = lambda: oracle.render_frame(syn["H"], W, syn["focal"], syn["c2w"], syn["near"], syn["far"], syn["bc"], pc, pf,
+                                      syn["aud"], syn["expr"], syn["latent"], rows=(0, nrows), **kw)
+    times = []
     with torch.no_grad():
-        oracle.render_frame(syn["H"], W, syn["focal"], syn["c2w"], syn["near"], syn["far"], syn["bc"], pc, pf,
-                            syn["aud"], syn["expr"], syn["latent"], rows=(0, 1), **kw)  # warm (512 rays)
-        t0 = time.perf_counter()
-        ref = oracle.render_frame(syn["H"], W, syn["focal"], syn["c2w"], syn["near"], syn["far"], syn["bc"], pc, pf,
-                                  syn["aud"], syn["expr"], syn["latent"], rows=(0, nrows), **kw)
-        dt = time.perf_counter() - t0
+        ref = run()   # warm-up on the timed tile
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            ref = run()
+            times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     rays = nrows * W
     out = {"value": rays * 256 / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"first {rays} rays ({nrows} rows) of the same 512x512 frame, 64+128 samples, "
-                     f"PyTorch-CPU oracle, 1 warm-up + 1 timed run ({dt:.1f} s)"}
+           "cpu": cpu_model(), "s_per_frame_extrapolated": dt * (syn["H"] * W) / rays,
+           "sample": f"first {rays} rays ({nrows} rows) of the same {syn['H']}x{W} frame, 64+128 samples, "
+                     f"PyTorch-CPU oracle, 1 warm-up on that tile + median of {runs} timed runs "
+                     f"({', '.join(f'{t:.2f}' for t in times)} s)"}
     psnr = None
     if gpu_rgb_band is not None and band_row0 == 0 and gpu_rgb_band.shape[0] >= nrows:
         mse = float(((gpu_rgb_band[:nrows].cpu() - ref["rgb_map"]) ** 2).mean())
@@ -189,21 +264,44 @@ def bench_train(args):
     latent_codes = torch.ones(8, 32, device=dev, requires_grad=True)
     opt = T_.make_optimizer(net, latent_codes)
     data = (batch_rays[None], tgt, bg, auds[None], torch.zeros(1, H, W, 3), pose, syn["expr"][None].to(dev), torch.tensor([3]))
+    lib = idealnerf_amd._lib.load()
     for i in range(args.warmup):
         T_.train_step(net, opt, data, latent_codes, i, 8)
     torch.cuda.synchronize()
+    lib.idealnerf_profile_begin()
     t0 = time.perf_counter()
     for i in range(args.steps):
         info = T_.train_step(net, opt, data, latent_codes, args.warmup + i, 8)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kinds = profile_kinds(lib)
     samples = len(sel) * 256 * args.steps
+    # the three MFMA kernel families of a step; forward and delta chain count the points they were launched on,
+    # the dW GEMMs the step's points (one launch per layer contracts over all of them)
+    fl = {"mlp_fwd_save": samples * FLOP_PER_SAMPLE, "delta_chain": samples * FLOP_PER_SAMPLE_DX, "dw_gemm": samples * FLOP_PER_SAMPLE}
+    split = {k: {"ms_per_step": kinds[k][0] / args.steps, "launches_per_step": kinds[k][1] / args.steps,
+                 "algorithmic_tflops": fl[k] / (kinds[k][0] * 1e-3) / 1e12 if kinds[k][0] > 0 else None,
+                 "frac_of_fp32_mfma_peak": fl[k] / (kinds[k][0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if kinds[k][0] > 0 else None}
+             for k in fl}
+    k_ms = sum(kinds[k][0] for k in fl)
+    ach = sum(fl.values()) / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None
     print(json.dumps({"metric": "train ray-samples/sec (N_rand=3072, 64+128, fwd+bwd+Adam)", "value": samples / dt,
                       "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-                      "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "f32", "data": "synthetic",
                       "config": {"workload": "BASELINE configs[2]: May HeadNeRF train step, N_rand=3072 mouth_rays=512 "
                                              "dim_aud=64 dim_expr=76, perturb=1"},
-                      "algorithmic_tflops": samples * 3 * FLOP_PER_SAMPLE / dt / 1e12, "final_loss": float(info["loss"])}))
+                      "roofline": {"bound": "mfma", "kernel": "idn::mlp_f32_kernel<kModeRays, SAVE> + idn::delta_chain_kernel + "
+                                                             "idn::gemm_tn_kernel (the step's three fp32-MFMA kernel families)",
+                                   "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / PEAK_F32_MFMA_TFLOPS if ach else None, "traffic": None,
+                                   "flop_per_sample": FLOP_PER_SAMPLE_STEP, "kernels": split,
+                                   "kernel_time_share": (k_ms * 1e-3) / dt,
+                                   "whole_step_algorithmic_tflops": samples * FLOP_PER_SAMPLE_STEP / dt / 1e12,
+                                   "note": "achieved = algorithmic FLOP of the three families / their summed HIP-event time; "
+                                           "the rest of a step is compositing fwd/bwd, sampling, partial-slab reductions, "
+                                           "audio net, Adam"},
+                      "final_loss": float(info["loss"])}))
 
 
 def bench_torso(args):
@@ -242,15 +340,18 @@ def bench_torso(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib = idealnerf_amd._lib.load()
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
         fence()
+        lib.idealnerf_profile_begin()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             frame = step()
         fence()
         dt = time.perf_counter() - t0
+    k_ms, k_n, k_pts = profile_kinds(lib)["mlp_fwd"]
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -272,9 +373,52 @@ def bench_torso(args):
                           "frames_per_s": world * args.steps / dt,
                           "config": {"workload": f"BASELINE configs[4]: HeadNeRF+TorsoNeRF composite, {H}x{W}, frame-parallel",
                                      "nets": "head C=235 (aud 64, expr 76, latent 32) + torso C=169 (aud 64 + pose PE 42)"},
+                          "roofline": {"bound": "mfma", "kernel": f"fused PE + FaceNeRF MLP forward, {prec} arithmetic (rank 0's launches)",
+                                       "achieved": k_pts * FLOP_PER_SAMPLE / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None,
+                                       "peak": mode_peaks()[prec], "unit": "TFLOP/s",
+                                       "frac": k_pts * FLOP_PER_SAMPLE / (k_ms * 1e-3) / 1e12 / mode_peaks()[prec] if k_ms > 0 else None,
+                                       "traffic": None, "launches": k_n, "avg_launch_ms": k_ms / k_n if k_n else None,
+                                       "flop_per_sample": FLOP_PER_SAMPLE, "kernel_time_share": (k_ms * 1e-3) / dt},
                           "finite": bool(torch.isfinite(frame).all()), "psnr_vs_fp32_frame_db": psnr}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def network_api_measurement(args, syn, coarse, fine, c_abi_value, c_abi_tile, frames=3):
+    """The same frame through the drop-in surface a reference caller uses: ``Network.forward([data, global_step,
+    dataset_size])`` in eval mode with the reference's default ``chunk = 8192`` (helper.py:54), audio net and
+    conditioning fold included, against the number measured on ``ops.render_rays_fwd`` above."""
+    from idealnerf_amd.audio_exp_nerf import Network
+    from idealnerf_amd.helper import RenderConfig
+    dev = c_abi_tile.device
+    H, W = syn["H"], syn["W"]
+    cfg = RenderConfig(perturb=0.0, chunk=8192, near=syn["near"], far=syn["far"])
+    torch.manual_seed(0)
+    net = Network(H, W, syn["focal"], syn["near"], syn["far"], 8192, None, 64, 128, args=cfg).to(dev).eval()
+    net.face_nerf_coarse.load_state_dict(coarse.state_dict())
+    net.face_nerf_fine.load_state_dict(fine.state_dict())
+    net.face_nerf_coarse.precision, net.face_nerf_fine.precision = coarse.precision, fine.precision
+    auds = torch.randn(8, 16, 29, device=dev)
+    pose = torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
+    data = (torch.zeros(1, 2, 1, 3), torch.zeros(1, 3), syn["bc"].to(dev)[None], auds[None], torch.zeros(1, H, W, 3), pose[None],
+            syn["expr"].to(dev)[None], syn["latent"].to(dev), torch.tensor([3]))
+    with torch.no_grad():
+        net([data, 0, 8])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            rgb, disp, acc, last_w, extras = net([data, 0, 8])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / frames
+        # same pixels as the C-ABI frame when the audio feature is the bench's: re-render with it for the check
+        net_rgb = net.render_dynamic_face(H, W, syn["focal"], expr=syn["expr"].to(dev), poses=pose, latent_code=syn["latent"].to(dev),
+                                          render_poses=pose[:3, :4], chunk=8192, near=syn["near"], far=syn["far"],
+                                          bc_rgb=syn["bc"].to(dev), aud_para=syn["aud"].to(dev))[0]
+    v = H * W * 256 / dt
+    return {"value": v, "unit": "ray-samples/s", "ms_per_frame": dt * 1e3, "ratio_to_c_abi": v / c_abi_value,
+            "identical_to_c_abi_frame": bool(torch.equal(net_rgb.reshape(-1, 3), c_abi_tile.reshape(-1, 3))),
+            "call": "Network.forward([data, global_step, dataset_size]) in eval mode, chunk=8192, AudioNet + both folds per "
+                    "frame; batchify_rays issues one C call per frame when perturb == 0"}
 
 
 def main():
@@ -383,25 +527,13 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
-        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the
-        # process, so the figure comes from the committed rocprofv3 --pmc passes of this same command
-        # (tools/profile_round.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes).
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_mlp_{args.precision}_final.json")))
-            if H == 512 and world == 1:
-                traffic = pmc["hbm_traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_source = pmc_traffic(args.precision)
+        if not (H == 512 and world == 1):
+            traffic, traffic_source = None, {"file": None, "reason": "PMC summaries exist for the 512x512 single-GPU run only"}
         samples = H * W * (S + S + Ni) * args.steps
         value = samples / dt
         ach = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12 if k_ms.value > 0 else None
-        # a bf16x3 kernel issues three bf16 MFMAs per algorithmic product: it is priced against peak / 3
-        # mixed = two kernels with two peaks (1/4 of the samples on the fp32 path, 3/4 on bf16x3): the blended
-        # peak is total FLOP / (coarse FLOP / fp32 peak + fine FLOP / (bf16 peak / 3)), so frac = ideal time / actual
-        mixed_peak = 1.0 / (0.25 / PEAK_F32_MFMA_TFLOPS + 0.75 / (PEAK_BF16_MFMA_TFLOPS / 3.0))
-        peaks = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3.0,
-                 "bf16": PEAK_BF16_MFMA_TFLOPS, "mixed": mixed_peak}   # the dense fp16 and bf16 MFMA peaks are equal on gfx950
+        peaks = mode_peaks()
         peak = peaks[args.precision]
         kname = {"f32": "idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)",
                  "bf16x3": "idn::mlp_bf16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 bf16 MFMAs per product)",
@@ -422,7 +554,7 @@ def main():
                        "band_rows": [b - a for a, b in parallel.all_bands(H, world)]},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (ach / peak) if ach else None, "traffic": traffic,
+                         "frac": (ach / peak) if ach else None, "traffic": traffic, "traffic_source": traffic_source,
                          "launches": k_n.value, "avg_launch_ms": (k_ms.value / k_n.value) if k_n.value else None,
                          "flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": (k_pts.value / k_n.value) if k_n.value else None,
                          "kernel_time_share": (k_ms.value * 1e-3) / dt if dt > 0 else None,
@@ -466,6 +598,8 @@ def main():
                                               "psnr_db": float(-10.0 * torch.log10((diff ** 2).mean().clamp_min(1e-30)))},
                     "note": notes[other]}
             set_mode(args.precision)
+        if world == 1 and not args.no_f32_mode:
+            res["network_api"] = network_api_measurement(args, syn, coarse, fine, value, tile)
         if world == 1 and not args.no_cpu_baseline:
             pc = {k: v.detach().cpu() for k, v in coarse.state_dict().items()}
             pf = {k: v.detach().cpu() for k, v in fine.state_dict().items()}

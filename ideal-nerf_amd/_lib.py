@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("IDN_LIB") or os.path.join(HERE, "libidealnerf.so")
 
 IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16, IDN_PREC_FP16X3 = 0, 1, 2, 3
 RAY_FLOATS = 11
+PROF_KINDS = ("mlp_fwd", "mlp_fwd_save", "delta_chain", "dw_gemm")   # IDN_PROF_* of include/idealnerf.h
 
 fp = C.c_void_p  # device pointers travel as integers
 
@@ -72,6 +73,7 @@ PROTOTYPES = {
                                      fp, C.c_int64, C.c_int, fp, fp, fp, fp, fp, fp, fp, C.c_size_t, fp]),
     "idealnerf_profile_begin": (None, []),
     "idealnerf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "idealnerf_profile_end_kinds": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

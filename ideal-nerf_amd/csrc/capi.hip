@@ -59,8 +59,9 @@ static int g_prof_n = 0;
 static hipEvent_t g_prof_ev[kProfSlots][2];
 static int g_prof_created = 0;
 static int64_t g_prof_points[kProfSlots];
+static int g_prof_kind[kProfSlots];
 
-ProfScope::ProfScope(hipStream_t s_, int64_t points) : slot(-1), s(s_) {
+ProfScope::ProfScope(hipStream_t s_, int64_t points, int kind) : slot(-1), s(s_) {
     if (!g_prof_on || g_prof_n >= kProfSlots) return;
     slot = g_prof_n++;
     if (slot >= g_prof_created) {
@@ -69,6 +70,7 @@ ProfScope::ProfScope(hipStream_t s_, int64_t points) : slot(-1), s(s_) {
         g_prof_created = slot + 1;
     }
     g_prof_points[slot] = points;
+    g_prof_kind[slot] = (kind >= 0 && kind < IDN_PROF_KINDS) ? kind : 0;
     (void)hipEventRecord(g_prof_ev[slot][0], s);
 }
 ProfScope::~ProfScope() {
@@ -258,20 +260,35 @@ void idealnerf_profile_begin(void) {
     g_prof_on = true;
 }
 
-int idealnerf_profile_end(double* total_ms, int64_t* launches, int64_t* points) {
+int idealnerf_profile_end_kinds(double* total_ms, int64_t* launches, int64_t* points) {
     g_prof_on = false;
-    double ms = 0;
-    int64_t pts = 0;
+    double ms[IDN_PROF_KINDS] = {0};
+    int64_t n[IDN_PROF_KINDS] = {0}, pts[IDN_PROF_KINDS] = {0};
     for (int i = 0; i < g_prof_n; ++i) {
         IDN_HIP_CHECK(hipEventSynchronize(g_prof_ev[i][1]));
         float t = 0;
         IDN_HIP_CHECK(hipEventElapsedTime(&t, g_prof_ev[i][0], g_prof_ev[i][1]));
-        ms += t;
-        pts += g_prof_points[i];
+        const int k = g_prof_kind[i];
+        ms[k] += t;
+        n[k] += 1;
+        pts[k] += g_prof_points[i];
     }
-    if (total_ms) *total_ms = ms;
-    if (launches) *launches = g_prof_n;
-    if (points) *points = pts;
+    for (int k = 0; k < IDN_PROF_KINDS; ++k) {
+        if (total_ms) total_ms[k] = ms[k];
+        if (launches) launches[k] = n[k];
+        if (points) points[k] = pts[k];
+    }
+    return IDN_OK;
+}
+
+int idealnerf_profile_end(double* total_ms, int64_t* launches, int64_t* points) {
+    double ms[IDN_PROF_KINDS];
+    int64_t n[IDN_PROF_KINDS], pts[IDN_PROF_KINDS];
+    if (int e = idealnerf_profile_end_kinds(ms, n, pts)) return e;
+    // the forward MLP launches, with or without saved activations
+    if (total_ms) *total_ms = ms[IDN_PROF_MLP_FWD] + ms[IDN_PROF_MLP_FWD_SAVE];
+    if (launches) *launches = n[IDN_PROF_MLP_FWD] + n[IDN_PROF_MLP_FWD_SAVE];
+    if (points) *points = pts[IDN_PROF_MLP_FWD] + pts[IDN_PROF_MLP_FWD_SAVE];
     return IDN_OK;
 }
 

@@ -153,7 +153,7 @@ struct LaunchSetup {
 struct ProfScope {
     int slot;
     hipStream_t s;
-    ProfScope(hipStream_t s, int64_t points);
+    ProfScope(hipStream_t s, int64_t points, int kind = IDN_PROF_MLP_FWD);
     ~ProfScope();
 };
 

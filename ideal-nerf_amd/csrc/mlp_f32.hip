@@ -460,7 +460,7 @@ int launch_mlp_f32(const float* packed, const float* folded, const float* x, con
     const int64_t ntiles = (n_points + 127) / 128;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, acts, (long)p_pad};
-    ProfScope prof(s, n_points);
+    ProfScope prof(s, n_points, acts ? IDN_PROF_MLP_FWD_SAVE : IDN_PROF_MLP_FWD);
     if (acts) {
         if (x || pts) return fail(IDN_EUNSUPPORTED, "activation saving is only built for the rays+z input mode");
         hipLaunchKernelGGL((mlp_f32_kernel<kModeRays, true>), dim3(grid), dim3(256), kMlpLdsTrain, s, a);

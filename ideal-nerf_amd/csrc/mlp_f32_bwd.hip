@@ -321,6 +321,7 @@ int launch_delta_chain(const float* packed_bwd, const float* acts, int64_t p_pad
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     DeltaArgs a{packed_bwd, acts, (long)p_pad, d_rgb, dv0, dv2, dv1, {}};
     for (int l = 0; l < 8; ++l) a.da[l] = da[l];
+    ProfScope prof(s, p_pad, IDN_PROF_DELTA_CHAIN);
     hipLaunchKernelGGL(delta_chain_kernel, dim3(grid), dim3(256), kDeltaLds, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;

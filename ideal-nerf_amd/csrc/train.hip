@@ -392,6 +392,7 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
             return IDN_OK;
         }, &num_cu))
         return e;
+    ProfScope prof(s, P, IDN_PROF_DW_GEMM);
     if (ntw == 4 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, lds, s, g);
     else if (ntw == 4 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), grid, block, lds, s, g);
     else if (ntw == 2 && ktw == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, lds, s, g);

@@ -291,6 +291,16 @@ int idealnerf_to8b(const float* rgb, int64_t n_pixels, int swap_rb, uint8_t* out
 void idealnerf_profile_begin(void);
 int idealnerf_profile_end(double* total_ms, int64_t* launches, int64_t* points);
 
+/* The same measurement split by kernel family (arrays of IDN_PROF_KINDS entries each; any may be NULL):
+ * the training step's roofline needs its three MFMA kernels separately.  For the dW GEMMs `points` counts
+ * the points each launch contracted over (one launch per layer). */
+#define IDN_PROF_MLP_FWD 0      /* fused PE + MLP forward (inference) */
+#define IDN_PROF_MLP_FWD_SAVE 1 /* the same with saved activations (training forward) */
+#define IDN_PROF_DELTA_CHAIN 2  /* fused backward delta chain */
+#define IDN_PROF_DW_GEMM 3      /* dW = delta^T . activation GEMMs (+ bias column sums) */
+#define IDN_PROF_KINDS 4
+int idealnerf_profile_end_kinds(double* total_ms, int64_t* launches, int64_t* points);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,17 @@ def main():
                 res[k.lower() + "_fraction"] = mean[k] / mean["SQ_WAVE_CYCLES"]
     if "GRBM_GUI_ACTIVE" in mean and durs:
         res["effective_clock_ghz"] = mean["GRBM_GUI_ACTIVE"] / 8.0 / (res["mean_launch_ms_under_pmc"] * 1e-3) / 1e9
+    # identity of what was profiled: bench.py reports `traffic` only while the kernel sources still match
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(root, "ideal-nerf_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    res["kernel_source_sha16"] = h.hexdigest()[:16]
+    res["commit"] = os.environ.get("IDN_COMMIT")   # the GPU box has no .git: tools/profile_round.sh passes it in
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
