@@ -53,6 +53,28 @@ def build_diag(verbose=True, define="-DIDN_DIAG", tag="diag"):
     return lib
 
 
+def build_variant(tag, define, sources, verbose=True):
+    """libidealnerf_<tag>.so for same-box A/Bs (tools/ab_bench.sh): only `sources` are recompiled with the
+    extra defines, every other object comes from the regular build (run build() first)."""
+    obj = os.path.join(OBJ, tag)
+    os.makedirs(obj, exist_ok=True)
+
+    def one(src):
+        o = os.path.join(obj, src.replace(".hip", ".o"))
+        cmd = [hipcc()] + FLAGS + define.split() + ["-c", os.path.join(CSRC, src), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return o
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        changed = dict(zip(sources, ex.map(one, sources)))
+    objs = [changed.get(s, os.path.join(OBJ, s.replace(".hip", ".o"))) for s in SOURCES]
+    lib = os.path.join(HERE, f"libidealnerf_{tag}.so")
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
+    return lib
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -85,5 +107,8 @@ def build(force=False, verbose=True):
 if __name__ == "__main__":
     if "--diag" in sys.argv:
         print(build_diag())
+    elif "--variant" in sys.argv:   # --variant <tag> "<-D...>" src.hip [src.hip ...]
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2], sys.argv[i + 3:]))
     else:
         print(build(force="--force" in sys.argv))

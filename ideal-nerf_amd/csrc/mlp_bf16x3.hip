@@ -43,9 +43,13 @@ __device__ __forceinline__ f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
 // (v_cvt_pkrtz_f16_f32, never overflows to inf); lo = x - hi is exact in fp32 and carries the next 11 bits.
 __device__ __forceinline__ void split2(float x0, float x1, float& hi_w, float& lo_w) {
     const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const float f0 = (float)h[0], f1 = (float)h[1];
     hi_w = __builtin_bit_cast(float, h);
-    lo_w = __builtin_bit_cast(float, __builtin_amdgcn_cvt_pkrtz(x0 - f0, x1 - f1));
+    // x - float(h) in one instruction per value: v_fma_mix_f32 reads the f16 half directly (op_sel_hi marks
+    // source 0 as f16, op_sel picks its half).  Inputs are ordinary VALU results, never raw MFMA outputs.
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi_w), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi_w), "v"(x1));
+    lo_w = __builtin_bit_cast(float, __builtin_amdgcn_cvt_pkrtz(l0, l1));
 }
 #else
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -62,8 +66,9 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
 // one packed word of the hi part and of the lo part from two fp32 values
 __device__ __forceinline__ void split2(float x0, float x1, float& hi_w, float& lo_w) {
     const unsigned h = cvt_pk_bf16(x0, x1);
-    const float f0 = __uint_as_float(h << 16), f1 = __uint_as_float(h & 0xffff0000u);
     hi_w = __uint_as_float(h);
+    // (the two subtractions as one v_pk_add_f32: same-box A/B -0.4 %, left as two)
+    const float f0 = __uint_as_float(h << 16), f1 = __uint_as_float(h & 0xffff0000u);
     lo_w = __uint_as_float(cvt_pk_bf16(x0 - f0, x1 - f1));
 }
 #endif

@@ -162,6 +162,10 @@ struct FragReader {
     // all but the newest `Newer` LDS reads of this wave have completed => v0, v1 are valid
     template <int Newer>
     static __device__ __forceinline__ void retire(f32x4& v0, f32x4& v1) {
+#ifdef IDN_TIMING_NO_FRAG_WAIT   // timing-only experiment (wrong results): is the fragment-read latency exposed?
+        asm volatile("" : "+v"(v0), "+v"(v1)::"memory");
+        return;
+#endif
         if constexpr (Newer == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
         else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(v0), "+v"(v1)::"memory");
     }
