@@ -12,6 +12,7 @@
 // Activations come from the training variant of the MLP kernel as row-major matrices
 // (idn_internal.h, "activation slab").  Everything is deterministic: no float atomics.
 #include "idn_internal.h"
+#include <type_traits>
 
 namespace idn {
 
@@ -33,7 +34,7 @@ struct TNArgs {
     float* part;               // [splits][N][K]
     int N, K;
     long P;                    // rows (multiple of 32)
-    int chunks_per_split;      // 32-row chunks per split
+    int chunks_per_split;      // kTnRows-row chunks per split
     float* cpart;              // optional [splits][N]: column sums of A (the bias gradient), from the k-block-0 workgroups
 };
 
@@ -41,11 +42,82 @@ struct TNArgs {
 // contiguous in global memory and in the tile, so one wave instruction moves 1 KiB of it): the
 // loads of chunk c+1 are in flight while chunk c is multiplied, one barrier per chunk.  (Single
 // buffered, every chunk paid its global-load latency: 70 % of the fp32 MFMA peak.)
+//
+// Operand reads.  MFMA row i of a wave's tile x is output channel NTW * i + x (not 32 x + i): a lane's NTW
+// A values of one point are then CONTIGUOUS in the row-major LDS tile and come with one ds_read_b128
+// (b64 / b32) instead of NTW strided ds_read_b32; the same for B.  The reads of point-pair s + 1 are
+// issued before the MFMAs of pair s from inline asm and retired by a counted wait tied to the
+// destination registers (hipcc issues such reads right before their use and waits lgkmcnt(0): an exposed
+// LDS round trip every 8 MFMAs, 12 % of the wave cycles parked, measured with SQ_WAIT_ANY).
+template <int N>
+struct LdsVec;
+template <>
+struct LdsVec<4> {
+    f32x4 v;
+    template <int OFF>
+    __device__ __forceinline__ void issue(uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); }
+    __device__ __forceinline__ float get(int j) const { return v[j]; }
+};
+template <>
+struct LdsVec<2> {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 v;
+    template <int OFF>
+    __device__ __forceinline__ void issue(uint32_t addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); }
+    __device__ __forceinline__ float get(int j) const { return v[j]; }
+};
+template <>
+struct LdsVec<1> {
+    float v;
+    template <int OFF>
+    __device__ __forceinline__ void issue(uint32_t addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); }
+    __device__ __forceinline__ float get(int) const { return v; }
+};
+template <int OFF>
+__device__ __forceinline__ void lds_read_f32(float& dst, uint32_t addr) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+// use of an asm-read value: not before the counted wait that precedes this call in program order
+__device__ __forceinline__ float landed(float& v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// all but the newest `NEWER` LDS reads of this wave have completed => a, b are valid
+template <int NEWER, class VA, class VB>
+__device__ __forceinline__ void lds_retire(VA& a, VB& b) {
+    if constexpr (NEWER == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v), "+v"(b.v)::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a.v), "+v"(b.v)::"memory");
+}
+template <int N, class F>
+__device__ __forceinline__ void tn_static_for(F&& f) {
+    if constexpr (N > 0) {
+        tn_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// Chunks of kTnRows points; kTnBufs LDS buffers: while chunk c is multiplied, the pieces of chunk c + 2 are
+// issued ONE PER POINT-PAIR STEP (a burst of 16 LDS-DMA instructions at the top of a chunk held the wave's
+// MFMA issue for ~10 % of the chunk), as `buffer_load ... lds` with a per-lane constant offset and a scalar
+// row offset (half the issue cost of the per-lane-pointer form), and they have a whole chunk to land: the
+// GEMM reads 2 KiB per point and layer for 131 kFLOP, i.e. it needs 2.5 TB/s of HBM at the MFMA peak.
+constexpr int kTnRows = 16, kTnBufs = 3;
+
+#ifdef IDN_DIAG   // diagnostic build only: where a <4,4> block spends its cycles (tools/diag_tn.py)
+__device__ unsigned long long g_tn_diag[8];   // total, wait (vmcnt + barrier), loop, epilogue, blocks, chunks
+#define TN_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TN_STAMP(v)
+#endif
+
 template <int NTW, int KTW>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     constexpr int BN = 64 * NTW, BK = 64 * KTW;
-    constexpr int kTileFloats = 32 * (BN + BK);            // one chunk: A tile then B tile
-    extern __shared__ __attribute__((aligned(16))) float tn_smem[];  // 2 * kTileFloats
+    constexpr int kTileFloats = kTnRows * (BN + BK);       // one chunk: A tile then B tile
+    constexpr int kSteps = kTnRows / 2;                    // point-pairs per chunk
+    constexpr int NP = NTW + KTW;                          // 1-KiB pieces per wave and chunk (<= kSteps)
+    static_assert(NP <= kSteps, "at most one piece per step");
+    extern __shared__ __attribute__((aligned(16))) float tn_smem[];  // kTnBufs * kTileFloats
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hh = lane >> 5;
@@ -59,69 +131,177 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
         for (int b = 0; b < KTW; ++b)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    unsigned long long dg_t0 = 0, dg_a = 0, dg_b = 0, dg_wait = 0, dg_loop = 0, dg_t1 = 0, dg_t2 = 0;
+    (void)dg_t0; (void)dg_a; (void)dg_b; (void)dg_wait; (void)dg_loop; (void)dg_t1; (void)dg_t2;
+    TN_STAMP(dg_t0);
     const long c_begin = (long)split * g.chunks_per_split;
     long c_end = c_begin + g.chunks_per_split;
-    const long c_total = g.P / 32;
+    const long c_total = g.P / kTnRows;
     if (c_end > c_total) c_end = c_total;
-    const bool do_colsum = g.cpart != nullptr && blockIdx.y == 0 && tid < BN;
+    const bool colsum_block = g.cpart != nullptr && blockIdx.y == 0;   // block-uniform
+    const bool do_colsum = colsum_block && tid < BN;
+    const int ccol = tid < BN ? tid : 0;                                  // threads beyond the tile re-read column 0 (unused)
     float csum = 0.0f;
 
-    // wave w moves every 4th 1-KiB piece of a tile: piece q holds float4 elements 64 q .. 64 q + 63
-    auto fill = [&](long c, int buf) {
-        const long p0 = c * 32;
-        float* As = tn_smem + buf * kTileFloats;
-        float* Bs = As + 32 * BN;
-#pragma unroll
-        for (int q = 0; q < BN / 32; ++q) {      // 32 * BN / 4 float4 = BN / 8 pieces, 4 waves -> BN / 32 each
-            const int piece = 4 * q + w, e = piece * 64 + lane, row = e / (BN / 4), c4 = e % (BN / 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (p0 + row) * g.lda + n0 + 4 * c4),
-                                             (__attribute__((address_space(3))) void*)(As + piece * 256), 16, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < BK / 32; ++q) {
-            const int piece = 4 * q + w, e = piece * 64 + lane, row = e / (BK / 4), c4 = e % (BK / 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.B + (p0 + row) * g.ldb + k0 + 4 * c4),
-                                             (__attribute__((address_space(3))) void*)(Bs + piece * 256), 16, 0, 0);
-        }
+    // A piece = 256 consecutive floats of a tile = 256 / BN rows of it.  Piece j (0 .. NTW-1) of wave w is
+    // tile piece NTW * w + j: rows (NTW * w + j) * (256 / BN) ..; lane l moves float4 l of the piece.
+    constexpr int kRowsPerPieceA = 256 / BN > 0 ? 256 / BN : 1, kRowsPerPieceB = 256 / BK > 0 ? 256 / BK : 1;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + n0), 0, 0xfffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + k0), 0, 0xfffffffc, 0x00020000);
+    const uint32_t voffA = ((lane / (BN / 4)) * g.lda + (lane % (BN / 4)) * 4) * 4;
+    const uint32_t voffB = ((lane / (BK / 4)) * g.ldb + (lane % (BK / 4)) * 4) * 4;
+    const uint32_t rowA = g.lda * 4, rowB = g.ldb * 4;    // bytes per matrix row
+    // piece ja (0 .. NTW-1) of this wave's share of the A tile / piece jb (0 .. KTW-1) of the B tile, for chunk c
+    // into buffer `buf`: scalar arithmetic only (a piece that had to choose between the two matrices cost a
+    // tree of scalar branches per point pair, ~10 % of the loop)
+    auto piece_a = [&](long c, int buf, int ja) {
+#ifdef IDN_TN_TIMING_NO_PIECES   // timing-only experiment (wrong results): the GEMM without its HBM traffic
+        if (c > c_begin + 1) return;
+#endif
+        const int pc = NTW * w + ja;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(tn_smem + buf * kTileFloats + pc * 256), 16, voffA,
+                                                 (uint32_t)((c * kTnRows + pc * kRowsPerPieceA) * rowA), 0, 0);
     };
-    if (c_begin < c_end) fill(c_begin, 0);
+    auto piece_b = [&](long c, int buf, int jb) {
+#ifdef IDN_TN_TIMING_NO_PIECES
+        if (c > c_begin + 1) return;
+#endif
+        const int pc = KTW * w + jb;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(tn_smem + buf * kTileFloats + kTnRows * BN + pc * 256), 16, voffB,
+                                                 (uint32_t)((c * kTnRows + pc * kRowsPerPieceB) * rowB), 0, 0);
+    };
+    auto piece = [&](long c, int buf, int j) {   // prologue order: A pieces, then B pieces
+        if (j < NTW) piece_a(c, buf, j);
+        else if (j < NP) piece_b(c, buf, j - NTW);
+    };
+    // LDS byte addresses of this lane's operands of point-pair 0 in buffer 0: row hh, columns NTW * (32 wr + i) ..
+    const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)tn_smem;
+    const uint32_t a_addr0 = smem0 + (hh * BN + NTW * (32 * wr + i)) * 4;
+    const uint32_t b_addr0 = smem0 + (kTnRows * BN + hh * BK + KTW * (32 * wc + i)) * 4;
+    for (int j = 0; j < NP; ++j)
+        if (c_begin < c_end) piece(c_begin, 0, j);
+    for (int j = 0; j < NP; ++j)
+        if (c_begin + 1 < c_end) piece(c_begin + 1, 1, j);
+    int buf = 0;
     for (long c = c_begin; c < c_end; ++c) {
-        const int buf = (int)((c - c_begin) & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk c have landed
-        __syncthreads();                                   // everyone's have; everyone is done with the other buffer
-        if (c + 1 < c_end) fill(c + 1, buf ^ 1);
-        const float* As = tn_smem + buf * kTileFloats;
-        const float* Bs = As + 32 * BN;
-        if (do_colsum) {   // the delta tile is in LDS anyway: its column sums are the bias gradient (1 % more VALU)
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) csum += As[r * BN + tid];
+        TN_STAMP(dg_a);
+        // this wave's pieces of chunk c have landed (those of chunk c + 1, issued later, may still be in flight)
+        if (c + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // everyone's have; everyone is done with chunk c - 1, whose buffer chunk c + 2 now takes.  A raw barrier:
+        // __syncthreads() would add its own vmcnt(0) and wait for the pieces of chunk c + 1 as well
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TN_STAMP(dg_b);
+#ifdef IDN_DIAG
+        dg_wait += dg_b - dg_a;
+#endif
+        const int buf2 = buf >= 1 ? buf - 1 : kTnBufs - 1;   // (buf + 2) % 3
+        const bool more = c + 2 < c_end;
+        // The delta tile is in LDS anyway: its column sums are the bias gradient.  The kTnRows reads of column
+        // `tid` go out first (inline asm, like the operand reads) and are added after the first counted wait of
+        // the loop below, which covers them (LDS returns in order): read by plain loads they parked every wave
+        // for two LDS round trips per chunk, 5 % of it.
+        float cs[kTnRows];
+        if (colsum_block) {
+            const uint32_t caddr = smem0 + buf * (kTileFloats * 4) + ccol * 4;
+            tn_static_for<kTnRows>([&](auto R) {
+                lds_read_f32<decltype(R)::value * BN * 4>(cs[decltype(R)::value], caddr);
+            });
         }
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int prow = 2 * s + hh;
-            float a[NTW], b[KTW];
-#pragma unroll
-            for (int x = 0; x < NTW; ++x) a[x] = As[prow * BN + 32 * NTW * wr + 32 * x + i];
-#pragma unroll
-            for (int y = 0; y < KTW; ++y) b[y] = Bs[prow * BK + 32 * KTW * wc + 32 * y + i];
+        // kSteps point-pairs, two per loop iteration (one per register buffer); the loop is kept rolled: fully
+        // unrolled, hipcc shuffles the 256 accumulator registers between steps (~500 v_accvgpr_mov per chunk)
+        LdsVec<NTW> a0v, a1v;
+        LdsVec<KTW> b0v, b1v;
+        auto mm = [&](const LdsVec<NTW>& av, const LdsVec<KTW>& bv) {
+#ifdef IDN_TN_TIMING_NO_MFMA     // timing-only experiment (wrong results): the data movement alone
+            acc[0][0][0] += av.get(0) * bv.get(0);
+            return;
+#endif
 #pragma unroll
             for (int x = 0; x < NTW; ++x)
 #pragma unroll
-                for (int y = 0; y < KTW; ++y) acc[x][y] = mfma32(a[x], b[y], acc[x][y]);
+                for (int y = 0; y < KTW; ++y) acc[x][y] = mfma32(av.get(x), bv.get(y), acc[x][y]);
+        };
+        constexpr int kStepA = 2 * BN * 4, kStepB = 2 * BK * 4;   // bytes from one point-pair to the next
+        uint32_t pa = a_addr0 + buf * (kTileFloats * 4), pb = b_addr0 + buf * (kTileFloats * 4);
+        a0v.template issue<0>(pa);
+        b0v.template issue<0>(pb);
+        // first half of the chunk: the A pieces of chunk c + 2 (one per point pair), second half: its B pieces
+        static_assert(NTW <= kSteps / 2 && KTW <= kSteps / 2, "pieces of one matrix fit one half of a chunk");
+#pragma unroll 1
+        for (int it = 0; it < kSteps / 4; ++it) {
+            a1v.template issue<kStepA>(pa);
+            b1v.template issue<kStepB>(pb);
+            if (more && 2 * it < NTW) piece_a(c + 2, buf2, 2 * it);
+            lds_retire<2>(a0v, b0v);
+            if (colsum_block && it == 0) {   // the column reads were issued before a0v / b0v: they have landed too
+                tn_static_for<kTnRows>([&](auto R) { csum += landed(cs[decltype(R)::value]); });
+            }
+            mm(a0v, b0v);
+            pa += 2 * kStepA;
+            pb += 2 * kStepB;
+            a0v.template issue<0>(pa);
+            b0v.template issue<0>(pb);
+            if (more && 2 * it + 1 < NTW) piece_a(c + 2, buf2, 2 * it + 1);
+            lds_retire<2>(a1v, b1v);
+            mm(a1v, b1v);
         }
+#pragma unroll 1
+        for (int it = 0; it < kSteps / 4; ++it) {
+            a1v.template issue<kStepA>(pa);
+            b1v.template issue<kStepB>(pb);
+            if (more && 2 * it < KTW) piece_b(c + 2, buf2, 2 * it);
+            lds_retire<2>(a0v, b0v);
+            mm(a0v, b0v);
+            // the pair after next; past the last pair the read is repeated on the current rows (never used):
+            // one loop shape for all iterations keeps the accumulators where they are
+            const bool last = it == kSteps / 4 - 1;
+            pa = last ? pa : pa + 2 * kStepA;
+            pb = last ? pb : pb + 2 * kStepB;
+            a0v.template issue<0>(pa);
+            b0v.template issue<0>(pb);
+            if (more && 2 * it + 1 < KTW) piece_b(c + 2, buf2, 2 * it + 1);
+            lds_retire<2>(a1v, b1v);
+            mm(a1v, b1v);
+        }
+        lds_retire<0>(a0v, b0v);   // drain the repeated read before these registers are reused
+        buf = buf + 1 == kTnBufs ? 0 : buf + 1;
+        TN_STAMP(dg_a);
+#ifdef IDN_DIAG
+        dg_loop += dg_a - dg_b;
+#endif
     }
+    TN_STAMP(dg_t1);
     if (do_colsum) g.cpart[(long)split * g.N + n0 + tid] = csum;
+    // this lane holds, for tile (x, y) register r: output (n0 + NTW (32 wr + d_row(r, hh)) + x, k0 + KTW (32 wc + i) + y):
+    // the KTW values of one (x, r) are contiguous in a row of the partial block
     float* out = g.part + (long)split * g.N * g.K;
 #pragma unroll
     for (int x = 0; x < NTW; ++x)
 #pragma unroll
-        for (int y = 0; y < KTW; ++y)
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + NTW * (32 * wr + d_row(r, hh)) + x;
+            float* dst = out + (long)n * g.K + k0 + KTW * (32 * wc + i);
+            if constexpr (KTW == 4) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + 32 * NTW * wr + 32 * x + d_row(r, hh);
-                const int k = k0 + 32 * KTW * wc + 32 * y + i;
-                out[(long)n * g.K + k] = acc[x][y][r];
+                for (int y = 0; y < KTW; ++y) dst[y] = acc[x][y][r];
             }
+        }
+#ifdef IDN_DIAG
+    __builtin_amdgcn_s_waitcnt(0);
+    TN_STAMP(dg_t2);
+    if (NTW == 4 && KTW == 4 && tid == 0) {
+        atomicAdd(&g_tn_diag[0], dg_t2 - dg_t0);
+        atomicAdd(&g_tn_diag[1], dg_wait);
+        atomicAdd(&g_tn_diag[2], dg_loop);
+        atomicAdd(&g_tn_diag[3], dg_t2 - dg_t1);
+        atomicAdd(&g_tn_diag[4], 1ull);
+        atomicAdd(&g_tn_diag[5], (unsigned long long)(c_end - c_begin));
+    }
+#endif
 }
 
 // out[n*ldo + k] = sum_s part[s][n][k],  n < rows, k < cols  (rows/cols may be smaller than N/K: padding dropped)
@@ -373,7 +553,7 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
     else if (N == 64 && K == 128) { ntw = 1; ktw = 2; }
     else return fail(IDN_EUNSUPPORTED, "gemm_tn: no instantiation for %d x %d", N, K);
     const int bx = N / (64 * ntw), by = K / (64 * ktw);
-    const long chunks = P / 32;
+    const long chunks = P / kTnRows;
     int splits = kMaxSplits / (bx * by);
     if (splits > chunks) splits = (int)chunks;
     if (splits < 1) splits = 1;
@@ -381,14 +561,14 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
     splits = (int)((chunks + cps - 1) / cps);
     TNArgs g{A, lda, B, ldb, part, N, K, (long)P, cps, cpart};
     const dim3 grid(bx, by, splits), block(256);
-    const size_t lds = 2 * 32 * (size_t)(64 * ntw + 64 * ktw) * 4;
+    const size_t lds = (size_t)kTnBufs * kTnRows * (size_t)(64 * ntw + 64 * ktw) * 4;
     static LaunchSetup setup;
     int num_cu = 0;
     if (int e = setup.get([]() -> int {
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<4, 4>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 512 * 4));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kTnBufs * kTnRows * 512 * 4));
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<4, 1>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 320 * 4));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kTnBufs * kTnRows * 320 * 4));
             return IDN_OK;
         }, &num_cu))
         return e;
@@ -493,5 +673,14 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
     }
     return IDN_OK;
 }
+
+#ifdef IDN_DIAG
+extern "C" int idealnerf_diag_tn_read(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tn_diag), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tn_diag), z, sizeof(z)) != hipSuccess) return -3;
+    return 0;
+}
+#endif
 
 }  // namespace idn

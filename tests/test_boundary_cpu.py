@@ -255,8 +255,8 @@ def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
                         "--cuda-device-only", os.path.join(csrc, name + ".hip"), "-o", str(out)], check=True)
         return str(out)
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
-        files = list(ex.map(compile_s, ["mlp_f32", "mlp_bf16x3", "mlp_f32_bwd"]))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        files = list(ex.map(compile_s, ["mlp_f32", "mlp_bf16x3", "mlp_f32_bwd", "train"]))
     for f in files:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), f, ""],
                            capture_output=True, text=True)
@@ -270,6 +270,19 @@ def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(bad)],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "written by an MFMA" in r.stdout
+    # the first check follows branches: a read that is only retired on the fall-through path is caught on the taken one
+    loop = tmp_path / "loop.s"
+    loop.write_text("_Z12fake_kernel2v:\n.LBB0_1:\n\t;;#ASMSTART\n\tds_read_b128 v[0:3], v9\n\t;;#ASMEND\n"
+                    "\ts_cbranch_scc1 .LBB0_3\n\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n"
+                    ".LBB0_3:\n\tv_add_f32_e32 v8, v1, v8\n\ts_cbranch_scc0 .LBB0_1\n\ts_endpgm\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(loop)],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "still in flight" in r.stdout
+    ok = tmp_path / "ok.s"
+    ok.write_text(loop.read_text().replace("s_cbranch_scc1 .LBB0_3\n", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(ok)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
 
 
 def test_config_files_parse_like_the_reference(idn):

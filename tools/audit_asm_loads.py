@@ -5,9 +5,9 @@ An `asm volatile("ds_read_b128 %0, ...")` destination counts, for the compiler, 
 the end of the asm statement -- but the data lands ~100+ cycles later.  Any compiler-generated
 instruction that reads or writes those registers before the asm `s_waitcnt lgkmcnt(N)` that
 retires them sees/destroys garbage (cdna_hip_programming.md 5.7).  This script walks each
-kernel in a .s file in program order (straight-line approximation), tracks the destination
-ranges of asm ds_reads and reports every non-asm instruction that touches a range while it is
-in flight.
+kernel in a .s file along every control-flow path (branches and loops followed), tracks the
+destination ranges of asm ds_reads and reports every non-asm instruction that touches a range
+while it is in flight.
 
 Second check, same walk: an inline-asm VALU instruction that reads a VGPR an MFMA wrote a few
 instructions earlier.  The hazard recogniser inserts the wait states an MFMA result needs before
@@ -27,22 +27,28 @@ def regs(tok):
         out.add((m.group(1), int(m.group(2))))
     return out
 
-def audit(lines, name):
-    inflight = []   # list of (regset, line_no) in issue order
-    mfma_dst = []   # (regset of VGPR destinations, instruction index) of recent MFMAs
-    in_asm = False
-    bad = 0
-    idx = 0
+def parse(lines):
+    """-> list of (line_no, code, in_asm) for real instructions, plus label -> instruction index."""
+    insts, labels, in_asm = [], {}, False
     for no, ln in lines:
         s = ln.strip()
-        if s.startswith(';;#ASMSTART') or '#ASMSTART' in s:
+        if '#ASMSTART' in s:
             in_asm = True; continue
         if '#ASMEND' in s:
             in_asm = False; continue
+        m = re.match(r'^(\.LBB\w+):', s)
+        if m:
+            labels[m.group(1)] = len(insts); continue
         if not s or s.startswith(';') or s.startswith('.') or s.endswith(':'):
             continue
-        code = s.split(';')[0]
-        idx += 1
+        insts.append((no, s.split(';')[0].strip(), in_asm))
+    return insts, labels
+
+
+def audit_mfma_to_asm_valu(insts, name):
+    """Second check, straight-line: an inline-asm VALU instruction reading a VGPR an MFMA wrote <= 20 instructions earlier."""
+    bad, mfma_dst = 0, []
+    for idx, (no, code, in_asm) in enumerate(insts):
         mfma_dst = [(r, i) for r, i in mfma_dst if idx - i <= 20]   # 16-pass MFMA -> VALU read: 18 wait states
         if in_asm and code.startswith('v_') and not code.startswith('v_mfma'):
             srcs = regs(' '.join(code.split()[2:]))
@@ -51,7 +57,7 @@ def audit(lines, name):
                 if hit:
                     bad += 1
                     if bad <= 12:
-                        print(f"  {name}: line {no}: asm `{code.strip()}` reads {sorted(hit)[:4]} written by an MFMA {idx - i} instructions earlier")
+                        print(f"  {name}: line {no}: asm `{code}` reads {sorted(hit)[:4]} written by an MFMA {idx - i} instructions earlier")
         if code.startswith('v_mfma'):
             d = {x for x in regs(code.split()[1].rstrip(',')) if x[0] == 'v'}
             if d:
@@ -59,29 +65,74 @@ def audit(lines, name):
         elif code.startswith(('v_', 'ds_read', 'global_load', 'buffer_load', 'scratch_load')) and len(code.split()) > 1:
             over = regs(code.split()[1].rstrip(','))          # a later writer owns the register again
             mfma_dst = [(r - over, i) for r, i in mfma_dst]
-        if in_asm:
-            if code.startswith('ds_read_b'):
-                dst = code.split()[1].rstrip(',')
-                inflight.append((regs(dst), no))
-            elif code.startswith('s_waitcnt'):
-                m = re.search(r'lgkmcnt\((\d+)\)', code)
-                if m:
-                    keep = int(m.group(1))
-                    inflight = inflight[len(inflight) - keep:] if keep else []
-            continue
-        if code.startswith('s_waitcnt') and 'lgkmcnt(0)' in code:
-            inflight = []   # compiler's own full LDS wait retires everything
-            continue
-        if code.startswith('s_barrier') or code.startswith('s_cbranch') or code.startswith('s_branch'):
-            continue
-        touched = regs(code)
-        for rs, at in inflight:
-            hit = touched & rs
-            if hit:
-                bad += 1
-                if bad <= 12:
-                    print(f"  {name}: line {no}: `{code.strip()}` touches {sorted(hit)[:4]} (asm ds_read at line {at} still in flight)")
     return bad
+
+
+def audit_inflight(insts, labels, name):
+    """First check, along every control-flow path (loops included): state = the ordered destinations of the asm
+    ds_reads still in flight.  Each (instruction, state) pair is explored once; the states a loop produces
+    repeat after an iteration, so the walk terminates (capped all the same)."""
+    bad, reported = 0, set()
+    seen = set()
+    work = [(0, ())]
+    steps = 0
+    while work and steps < 2_000_000:
+        idx, state = work.pop()
+        while idx < len(insts):
+            key = (idx, state)
+            if key in seen:
+                break
+            seen.add(key)
+            steps += 1
+            no, code, in_asm = insts[idx]
+            if in_asm:
+                if code.startswith('ds_read'):
+                    state = state + ((frozenset(regs(code.split()[1].rstrip(','))), no),)
+                    if len(state) > 32:   # a path that keeps issuing without ever retiring (the walk would not terminate)
+                        if ('unbounded', no) not in reported:
+                            reported.add(('unbounded', no))
+                            bad += 1
+                            print(f"  {name}: line {no}: more than 32 asm ds_reads in flight on some path (never retired)")
+                        break
+                elif code.startswith('s_waitcnt'):
+                    m = re.search(r'lgkmcnt\((\d+)\)', code)
+                    if m:
+                        keep = int(m.group(1))
+                        state = state[len(state) - keep:] if keep else ()
+                idx += 1
+                continue
+            if code.startswith('s_waitcnt'):
+                if 'lgkmcnt(0)' in code:
+                    state = ()   # the compiler's own full LDS wait retires everything
+                idx += 1
+                continue
+            if code.startswith('s_endpgm'):
+                break
+            if code.startswith('s_branch') or code.startswith('s_cbranch'):
+                tgt = labels.get(code.split()[1])
+                if tgt is not None:
+                    work.append((tgt, state))
+                if code.startswith('s_branch'):
+                    break
+                idx += 1
+                continue
+            if not code.startswith('s_barrier'):
+                touched = regs(code)
+                for rs, at in state:
+                    hit = touched & rs
+                    if hit and (no, at) not in reported:
+                        reported.add((no, at))
+                        bad += 1
+                        if bad <= 12:
+                            print(f"  {name}: line {no}: `{code}` touches {sorted(hit)[:4]} (asm ds_read at line {at} still in flight)")
+            idx += 1
+    return bad
+
+
+def audit(lines, name):
+    insts, labels = parse(lines)
+    return audit_inflight(insts, labels, name) + audit_mfma_to_asm_valu(insts, name)
+
 
 def main():
     path = sys.argv[1]
