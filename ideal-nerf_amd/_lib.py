@@ -42,7 +42,8 @@ class RenderArgs(C.Structure):
                                   "rgb0", "disp0", "acc0", "z_std", "last_weight0", "rgb_fg0",
                                   "tap_z_coarse", "tap_raw_coarse", "tap_weights_coarse", "tap_cdf", "tap_inds",
                                   "tap_z_samples", "tap_z_fine", "tap_raw_fine", "tap_weights_fine")] + \
-               [("workspace", fp), ("workspace_bytes", C.c_size_t), ("precision_fine_plus1", C.c_int)]
+               [("workspace", fp), ("workspace_bytes", C.c_size_t), ("precision_fine_plus1", C.c_int),
+                ("lindisp", C.c_int), ("white_bkgd", C.c_int), ("noise_coarse", fp), ("noise_fine", fp)]
 
 
 # name -> (restype, argtypes); mirrors include/idealnerf.h one to one
@@ -59,8 +60,8 @@ PROTOTYPES = {
     "idealnerf_frame_rays": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_int, C.c_int, fp, fp]),
     "idealnerf_to8b": (C.c_int, [fp, C.c_int64, C.c_int, fp, fp, fp]),
-    "idealnerf_coarse_depths": (C.c_int, [fp, fp, fp, C.c_int64, C.c_int, fp, fp]),
-    "idealnerf_composite_fwd": (C.c_int, [fp, fp, fp, fp, C.c_int64, C.c_int, C.POINTER(CompositeOut), fp]),
+    "idealnerf_coarse_depths": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, fp, fp]),
+    "idealnerf_composite_fwd": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.POINTER(CompositeOut), fp]),
     "idealnerf_sample_pdf_fwd": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp]),
     "idealnerf_sample_pdf_bins_fwd": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp, fp]),
     "idealnerf_invert_cdf": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp]),

@@ -123,18 +123,22 @@ class Network(nn.Module):
         NeRFs/TorsoNeRF/train_torso.py:326-345)."""
         args = self.args
         perturb = args.perturb if perturb is None else perturb
-        if lindisp or white_bkgd or raw_noise_std > 0.:
-            raise NotImplementedError("lindisp / white_bkgd / raw_noise_std are never enabled by the reference "
-                                      "(audio_exp_nerf.py:279,297-299) and are not compiled")
         if torch.is_grad_enabled() and self.training:
+            if white_bkgd or raw_noise_std > 0.:
+                raise NotImplementedError("white_bkgd / raw_noise_std are built for inference only: the reference's "
+                                          "training loop never sets them (audio_exp_nerf.py:297-299,534)")
             from .autograd import render_rays_apply
             return render_rays_apply(self, coarse, fine, rays, bc_rgb, aud_para, latent_code, expr, perturb, pytest,
-                                     with_fg)
+                                     with_fg, lindisp=lindisp)
         rays = rays.to(torch.float32).contiguous()
         bc_rgb = bc_rgb.to(torch.float32).contiguous()
         n, dev = rays.shape[0], rays.device
         S, Ni = args.N_samples, args.N_importance
         t_rand, u = self.draw_randoms(n, S, Ni, perturb, pytest, dev)
+        from .helper import draw_sigma_noise
+        # raw2outputs draws its noise per call, the coarse one first (baseline.py:353-361; numpy re-seeded each time under pytest)
+        noise_c = draw_sigma_noise((n, S), raw_noise_std, pytest, dev)
+        noise_f = draw_sigma_noise((n, S + Ni), raw_noise_std, pytest, dev) if Ni > 0 else None
         with torch.no_grad():
             fc = coarse.folded_bias(aud_para, expr, latent_code)
             ff = fine.folded_bias(aud_para, expr, latent_code) if Ni > 0 else None
@@ -144,7 +148,8 @@ class Network(nn.Module):
             out = ops.render_rays_fwd(rays, bc_rgb, coarse.packed_weights(), fc,
                                       fine.packed_weights() if Ni > 0 else None, ff,
                                       linspace01(S, dev), u, Ni, t_rand=t_rand, with_fg=with_fg, taps=taps or retraw,
-                                      precision=coarse.prec_code, precision_fine=fine.prec_code if Ni > 0 else None)
+                                      precision=coarse.prec_code, precision_fine=fine.prec_code if Ni > 0 else None,
+                                      lindisp=lindisp, white_bkgd=white_bkgd, noise_coarse=noise_c, noise_fine=noise_f)
         ret = {'rgb_map': out['rgb_map'], 'disp_map': out['disp_map'], 'acc_map': out['acc_map']}
         if with_fg:
             ret['rgb_map_fg'] = out['rgb_fg']
@@ -173,7 +178,9 @@ class Network(nn.Module):
                 t_rand = torch.rand((n, S), device=dev)
         u = None
         if Ni > 0:
-            if perturb == 0.:
+            if perturb == 0. and pytest:   # numpy's linspace under the test override (helper.py:286-290)
+                u = torch.Tensor(np.linspace(0., 1., Ni)).to(dev)
+            elif perturb == 0.:
                 u = linspace01(Ni, dev)
             elif pytest:
                 np.random.seed(0)
@@ -182,7 +189,7 @@ class Network(nn.Module):
                 u = torch.rand((n, Ni), device=dev)
         return t_rand, u
 
-    def raw2outputs(self, raw, z_vals, rays_d, bc_rgb, raw_noise_std=0, white_bkgd=False, pytest=False):
+    def raw2outputs(self, raw, z_vals, rays_d, bc_rgb, raw_noise_std=0., white_bkgd=False, pytest=False):
         from .helper import raw2outputs
         return raw2outputs(raw, z_vals, rays_d, bc_rgb, raw_noise_std, white_bkgd, pytest)
 

@@ -90,15 +90,15 @@ class RenderRaysFn(torch.autograd.Function):
     [, rgb_fg [, rgb_fg0, last_weight0]]  (middle group when N_importance > 0, last group for the
     torso variant).  disp / z_std carry no gradient."""
 
-    N_FIXED = 12  # non-parameter arguments of forward
+    N_FIXED = 13  # non-parameter arguments of forward
 
     @staticmethod
-    def forward(ctx, coarse, fine, S, Ni, with_fg, rays, bc, expr, t_rand, u, aud, latent, *params):
+    def forward(ctx, coarse, fine, S, Ni, with_fg, rays, bc, expr, t_rand, u, aud, latent, lindisp, *params):
         dev = rays.device
         f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
         aud_d, expr_d, lat_d = f32(aud), f32(expr), f32(latent)
         fc = coarse.folded_bias(aud_d, expr_d, lat_d)
-        z_c = ops.coarse_depths(rays, linspace01(S, dev), t_rand)
+        z_c = ops.coarse_depths(rays, linspace01(S, dev), t_rand, lindisp=lindisp)
         raw_c, acts_c = _train_query(coarse, fc, rays, z_c)
         comp_c = ops.composite_fwd(raw_c, z_c, rays, bc, with_fg=with_fg, with_weights=Ni > 0)
         ctx.nets, ctx.Ni, ctx.with_fg = (coarse, fine), Ni, with_fg
@@ -152,7 +152,8 @@ class RenderRaysFn(torch.autograd.Function):
         return (*fixed, *param_grads)
 
 
-def render_rays_apply(network, coarse, fine, rays, bc_rgb, aud_para, latent_code, expr, perturb, pytest, with_fg=False):
+def render_rays_apply(network, coarse, fine, rays, bc_rgb, aud_para, latent_code, expr, perturb, pytest, with_fg=False,
+                      lindisp=False):
     args = network.args
     rays = rays.detach().to(torch.float32).contiguous()
     bc = bc_rgb.detach().to(torch.float32).contiguous()
@@ -161,7 +162,8 @@ def render_rays_apply(network, coarse, fine, rays, bc_rgb, aud_para, latent_code
     t_rand, u = network.draw_randoms(n, S, Ni, perturb, pytest, dev)
     pc, pf = dict(coarse.named_parameters()), dict(fine.named_parameters())
     params = [pc[k] for k in PARAM_KEYS] + [pf[k] for k in PARAM_KEYS]
-    outs = RenderRaysFn.apply(coarse, fine, S, Ni, with_fg, rays, bc, expr, t_rand, u, aud_para, latent_code, *params)
+    outs = RenderRaysFn.apply(coarse, fine, S, Ni, with_fg, rays, bc, expr, t_rand, u, aud_para, latent_code, bool(lindisp),
+                              *params)
     ret = {'rgb_map': outs[0], 'disp_map': outs[1], 'acc_map': outs[2]}
     if Ni > 0:
         ret.update(rgb0=outs[3], disp0=outs[4], acc0=outs[5], z_std=outs[6], last_weight=outs[7])

@@ -83,7 +83,7 @@ using namespace idn;
 
 extern "C" {
 
-int idealnerf_version(void) { return 1; }
+int idealnerf_version(void) { return 2; }
 const char* idealnerf_last_error(void) { return g_err; }
 
 size_t idealnerf_packed_weight_floats(int precision) {
@@ -152,12 +152,12 @@ int idealnerf_frame_rays(const float* c2w, int H, int W, float focal, float cx, 
     return launch_frame_rays(c2w, H, W, focal, cx, cy, near_, far_, row0, nrows, rays_out, (hipStream_t)stream);
 }
 
-int idealnerf_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays,
+int idealnerf_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int lindisp, int64_t n_rays,
                             int n_samples, float* z, void* stream) {
     if (n_rays < 0 || n_samples < 1) return fail(IDN_EINVAL, "bad sizes");
     if (n_rays == 0) return IDN_OK;
     if (!rays || !t_vals || !z) return fail(IDN_EINVAL, "NULL pointer");
-    return launch_coarse_depths(rays, t_vals, t_rand, n_rays, n_samples, z, (hipStream_t)stream);
+    return launch_coarse_depths(rays, t_vals, t_rand, n_rays, n_samples, lindisp, z, (hipStream_t)stream);
 }
 
 int idealnerf_to8b(const float* rgb, int64_t n_pixels, int swap_rb, uint8_t* out, int* nonfinite_flag, void* stream) {
@@ -168,11 +168,12 @@ int idealnerf_to8b(const float* rgb, int64_t n_pixels, int swap_rb, uint8_t* out
 }
 
 int idealnerf_composite_fwd(const float* raw, const float* z, const float* rays, const float* bc_rgb,
-                            int64_t n_rays, int n_samples, const idn_composite_out* out, void* stream) {
+                            const float* sigma_noise, int white_bkgd, int64_t n_rays, int n_samples,
+                            const idn_composite_out* out, void* stream) {
     if (n_rays < 0) return fail(IDN_EINVAL, "n_rays < 0");
     if (n_rays == 0) return IDN_OK;
     if (!raw || !z || !rays || !bc_rgb || !out) return fail(IDN_EINVAL, "NULL pointer");
-    return launch_composite(raw, z, rays, bc_rgb, n_rays, n_samples, *out, (hipStream_t)stream);
+    return launch_composite(raw, z, rays, bc_rgb, n_rays, n_samples, sigma_noise, white_bkgd, *out, (hipStream_t)stream);
 }
 
 int idealnerf_sample_pdf_fwd(const float* z, const float* weights, const float* u, int u_per_ray, int64_t n_rays,
@@ -356,7 +357,7 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
         const int64_t c = (n - r0 < kRenderChunk) ? n - r0 : kRenderChunk;
         const float* rays = a->rays + r0 * IDN_RAY_FLOATS;
         const float* bc = a->bc_rgb + r0 * 3;
-        if (int e = launch_coarse_depths(rays, a->t_vals, off(a->t_rand, r0 * S), c, S, w.z_c, st)) return e;
+        if (int e = launch_coarse_depths(rays, a->t_vals, off(a->t_rand, r0 * S), c, S, a->lindisp, w.z_c, st)) return e;
         if (int e = launch_mlp(a->precision, a->packed_coarse, a->folded_coarse, nullptr, rays, w.z_c, nullptr, nullptr, c * S, S, w.raw_c, st)) return e;
         idn_composite_out co = {};
         const bool fine = Ni > 0;
@@ -367,7 +368,7 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
         co.weights = w.w_c;
         co.rgb_fg = off(fine ? a->rgb_fg0 : a->rgb_fg, r0 * 3);
         co.last_weight = off(fine ? a->last_weight0 : a->last_weight, r0);
-        if (int e = launch_composite(w.raw_c, w.z_c, rays, bc, c, S, co, st)) return e;
+        if (int e = launch_composite(w.raw_c, w.z_c, rays, bc, c, S, off(a->noise_coarse, r0 * S), a->white_bkgd, co, st)) return e;
         if (int e = tap(off(a->tap_z_coarse, r0 * S), w.z_c, (size_t)c * S * 4)) return e;
         if (int e = tap(off(a->tap_raw_coarse, r0 * S * 4), w.raw_c, (size_t)c * S * 16)) return e;
         if (int e = tap(off(a->tap_weights_coarse, r0 * S), w.w_c, (size_t)c * S * 4)) return e;
@@ -387,7 +388,7 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
         fo.weights = a->tap_weights_fine ? w.w_f : nullptr;
         fo.rgb_fg = off(a->rgb_fg, r0 * 3);
         fo.last_weight = off(a->last_weight, r0);
-        if (int e = launch_composite(w.raw_f, w.z_f, rays, bc, c, Sf, fo, st)) return e;
+        if (int e = launch_composite(w.raw_f, w.z_f, rays, bc, c, Sf, off(a->noise_fine, r0 * Sf), a->white_bkgd, fo, st)) return e;
         if (int e = tap(off(a->tap_z_fine, r0 * Sf), w.z_f, (size_t)c * Sf * 4)) return e;
         if (int e = tap(off(a->tap_raw_fine, r0 * Sf * 4), w.raw_f, (size_t)c * Sf * 16)) return e;
         if (int e = tap(off(a->tap_weights_fine, r0 * Sf), w.w_f, (size_t)c * Sf * 4)) return e;

@@ -96,7 +96,7 @@ int launch_frame_rays(const float* c2w_host, int H, int W, float focal, float cx
 // a3: coarse depths (audio_exp_nerf.py:306-330)
 // ---------------------------------------------------------------------------
 __global__ void coarse_depths_kernel(const float* rays, const float* t_vals, const float* t_rand, long n_rays, int S,
-                                     float* z) {
+                                     int lindisp, float* z) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_rays * S) return;
     const long r = idx / S;
@@ -104,6 +104,7 @@ __global__ void coarse_depths_kernel(const float* rays, const float* t_vals, con
     const float near_ = rays[r * IDN_RAY_FLOATS + 6], far_ = rays[r * IDN_RAY_FLOATS + 7];
     auto zlin = [&](int k) {
         const float t = t_vals[k];
+        if (lindisp) return 1.0f / (1.0f / near_ * (1.0f - t) + 1.0f / far_ * t);   // linear in inverse depth (:309-310)
         return near_ * (1.0f - t) + far_ * t;
     };
     float zz = zlin(s);
@@ -117,11 +118,11 @@ __global__ void coarse_depths_kernel(const float* rays, const float* t_vals, con
 }
 
 int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays, int S,
-                         float* z, hipStream_t s) {
+                         int lindisp, float* z, hipStream_t s) {
     const long total = (long)n_rays * S;
     if (total <= 0) return IDN_OK;
     hipLaunchKernelGGL(coarse_depths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rays, t_vals,
-                       t_rand, (long)n_rays, S, z);
+                       t_rand, (long)n_rays, S, lindisp, z);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }
@@ -162,7 +163,8 @@ int launch_to8b(const float* rgb, int64_t n_pixels, int swap_rb, unsigned char* 
 // ---------------------------------------------------------------------------
 template <int SPL>
 __global__ __launch_bounds__(256) void composite_kernel(const float4* raw, const float* z, const float* rays,
-                                                        const float* bc, long n_rays, int S, idn_composite_out out) {
+                                                        const float* bc, long n_rays, int S, const float* noise,
+                                                        int white_bkgd, idn_composite_out out) {
     const int lane = threadIdx.x & 63;
     const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;  // wave-uniform
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* raw, const
         const bool ok = s < S;
         zs[i] = ok ? zr[s] : 0.f;
         rw[i] = ok ? rawr[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (noise && ok) rw[i].w = rw[i].w + noise[ray * S + s];   // raw_noise_std: drawn by the caller (baseline.py:353-361)
     }
     zs[SPL] = __shfl_down(zs[0], 1, 64);  // first sample of the next lane
 
@@ -241,9 +244,10 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* raw, const
     if (lane == 0) {
         const float depth = (float)sd, acc = (float)sw;
         if (out.rgb_map) {
-            out.rgb_map[ray * 3 + 0] = (float)sr;
-            out.rgb_map[ray * 3 + 1] = (float)sg;
-            out.rgb_map[ray * 3 + 2] = (float)sb;
+            const float white = white_bkgd ? 1.0f - acc : 0.0f;   // rgb_map + (1 - acc_map) (baseline.py:372-373)
+            out.rgb_map[ray * 3 + 0] = white_bkgd ? (float)sr + white : (float)sr;
+            out.rgb_map[ray * 3 + 1] = white_bkgd ? (float)sg + white : (float)sg;
+            out.rgb_map[ray * 3 + 2] = white_bkgd ? (float)sb + white : (float)sb;
         }
         if (out.rgb_fg) {
             out.rgb_fg[ray * 3 + 0] = (float)fr;
@@ -257,17 +261,17 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* raw, const
 }
 
 int launch_composite(const float* raw, const float* z, const float* rays, const float* bc, int64_t n_rays, int S,
-                     const idn_composite_out& out, hipStream_t s) {
+                     const float* noise, int white_bkgd, const idn_composite_out& out, hipStream_t s) {
     if (n_rays <= 0) return IDN_OK;
     if (S < 2 || S > 64 * kMaxSpl) return fail(IDN_EUNSUPPORTED, "composite: n_samples %d outside [2, %d]", S, 64 * kMaxSpl);
     const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(raw);
     const int spl = (S + 63) / 64;
     switch (spl) {
-        case 1: hipLaunchKernelGGL(composite_kernel<1>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, out); break;
-        case 2: hipLaunchKernelGGL(composite_kernel<2>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, out); break;
-        case 3: hipLaunchKernelGGL(composite_kernel<3>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, out); break;
-        default: hipLaunchKernelGGL(composite_kernel<4>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, out); break;
+        case 1: hipLaunchKernelGGL(composite_kernel<1>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, noise, white_bkgd, out); break;
+        case 2: hipLaunchKernelGGL(composite_kernel<2>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, noise, white_bkgd, out); break;
+        case 3: hipLaunchKernelGGL(composite_kernel<3>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, noise, white_bkgd, out); break;
+        default: hipLaunchKernelGGL(composite_kernel<4>, grid, block, 0, s, r4, z, rays, bc, (long)n_rays, S, noise, white_bkgd, out); break;
     }
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;

@@ -185,9 +185,9 @@ int launch_frame_rays(const float* c2w, int H, int W, float focal, float cx, flo
                       int row0, int nrows, float* rays_out, hipStream_t s);
 int launch_to8b(const float* rgb, int64_t n_pixels, int swap_rb, unsigned char* out, int* flag, hipStream_t s);
 int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays, int S,
-                         float* z, hipStream_t s);
+                         int lindisp, float* z, hipStream_t s);
 int launch_composite(const float* raw, const float* z, const float* rays, const float* bc, int64_t n_rays, int S,
-                     const idn_composite_out& out, hipStream_t s);
+                     const float* noise, int white_bkgd, const idn_composite_out& out, hipStream_t s);
 int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in, const float* bins_in,
                       const float* u, int u_per_ray, int64_t n_rays, int S, int Ni, float* z_samples,
                       int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s);

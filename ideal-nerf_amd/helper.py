@@ -95,12 +95,22 @@ def _as_records(rays_d, z_like):
     return rec
 
 
+def draw_sigma_noise(shape, raw_noise_std, pytest, device):
+    """The density noise of raw2outputs as the reference draws it (baseline.py:353-361): randn * std, or --
+    under ``pytest`` -- numpy's UNIFORM rand(seed 0) * std (the reference's test override is uniform, not normal)."""
+    if not raw_noise_std > 0.0:
+        return None
+    if pytest:
+        np.random.seed(0)
+        return torch.Tensor(np.random.rand(*list(shape)) * raw_noise_std).to(device)
+    return torch.randn(tuple(shape), device=device) * raw_noise_std
+
+
 def raw2outputs(raw, z_vals, rays_d, bc_rgb, raw_noise_std=0.0, white_bkgd=False, pytest=False):
     """baseline.py:325-375 -> (rgb_map, disp_map, acc_map, weights, depth_map)."""
-    if raw_noise_std > 0.0 or white_bkgd:
-        raise NotImplementedError("raw_noise_std / white_bkgd are never enabled by the reference's Network "
-                                  "(audio_exp_nerf.py:297-299) and are not compiled")
-    o = ops.composite_fwd(raw.contiguous(), z_vals.contiguous(), _as_records(rays_d, z_vals), bc_rgb.contiguous())
+    noise = draw_sigma_noise(raw.shape[:-1], raw_noise_std, pytest, raw.device)
+    o = ops.composite_fwd(raw.contiguous(), z_vals.contiguous(), _as_records(rays_d, z_vals), bc_rgb.contiguous(),
+                          sigma_noise=noise, white_bkgd=white_bkgd)
     return o["rgb_map"], o["disp_map"], o["acc_map"], o["weights"], o["depth_map"]
 
 
@@ -109,7 +119,9 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
     dev = bins.device
     n, nb = bins.shape
     if u is None:
-        if det:
+        if det and pytest:   # the reference's test override replaces torch.linspace by numpy's (helper.py:286-290):
+            u = torch.Tensor(np.linspace(0., 1., N_samples)).to(dev)   # 8 of 128 values differ in the last bit
+        elif det:
             u = linspace01(N_samples, dev)
         elif pytest:
             np.random.seed(0)

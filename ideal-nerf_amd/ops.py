@@ -205,7 +205,7 @@ def to8b(rgb, swap_rb=False, nonfinite_flag=None) -> torch.Tensor:
     return out
 
 
-def coarse_depths(rays, t_vals, t_rand=None) -> torch.Tensor:
+def coarse_depths(rays, t_vals, t_rand=None, lindisp=False) -> torch.Tensor:
     lib = _lib.load()
     _shape(rays, "rays", None, RAY_FLOATS)
     _shape(t_vals, "t_vals", None)
@@ -213,20 +213,22 @@ def coarse_depths(rays, t_vals, t_rand=None) -> torch.Tensor:
     _shape(t_rand, "t_rand", n, S)
     with _Launch(rays, t_vals, t_rand) as L:
         z = torch.empty((n, S), dtype=torch.float32, device=rays.device)
-        check(lib.idealnerf_coarse_depths(_ptr(rays, "rays"), _ptr(t_vals, "t_vals"), _ptr(t_rand, "t_rand"), n, S,
-                                          z.data_ptr(), L.stream))
+        check(lib.idealnerf_coarse_depths(_ptr(rays, "rays"), _ptr(t_vals, "t_vals"), _ptr(t_rand, "t_rand"),
+                                          int(bool(lindisp)), n, S, z.data_ptr(), L.stream))
     return z
 
 
-def composite_fwd(raw, z, rays, bc_rgb, with_fg=False, with_weights=True) -> Dict[str, torch.Tensor]:
+def composite_fwd(raw, z, rays, bc_rgb, with_fg=False, with_weights=True, sigma_noise=None,
+                  white_bkgd=False) -> Dict[str, torch.Tensor]:
     lib = _lib.load()
     _shape(z, "z", None, None)
     n, S = z.shape
     _shape(raw, "raw", n, S, 4)
     _shape(rays, "rays", n, RAY_FLOATS)
     _shape(bc_rgb, "bc_rgb", n, 3)
+    _shape(sigma_noise, "sigma_noise", n, S)
     dev = z.device
-    with _Launch(raw, z, rays, bc_rgb) as L:
+    with _Launch(raw, z, rays, bc_rgb, sigma_noise) as L:
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         o = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n), depth_map=new(n), last_weight=new(n))
         if with_weights:
@@ -235,7 +237,7 @@ def composite_fwd(raw, z, rays, bc_rgb, with_fg=False, with_weights=True) -> Dic
             o["rgb_fg"] = new(n, 3)
         co = _lib.CompositeOut(**{k: v.data_ptr() for k, v in o.items()})
         check(lib.idealnerf_composite_fwd(_ptr(raw, "raw"), _ptr(z, "z"), _ptr(rays, "rays"), _ptr(bc_rgb, "bc_rgb"),
-                                          n, S, C.byref(co), L.stream))
+                                          _ptr(sigma_noise, "sigma_noise"), int(bool(white_bkgd)), n, S, C.byref(co), L.stream))
     return o
 
 
@@ -317,7 +319,8 @@ def _workspace(nbytes: int, device, stream) -> torch.Tensor:
 
 
 def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, n_importance,
-                    t_rand=None, with_fg=False, taps=False, precision=IDN_PREC_F32, precision_fine=None) -> Dict[str, torch.Tensor]:
+                    t_rand=None, with_fg=False, taps=False, precision=IDN_PREC_F32, precision_fine=None, lindisp=False,
+                    white_bkgd=False, noise_coarse=None, noise_fine=None) -> Dict[str, torch.Tensor]:
     """Network.render_rays forward (audio_exp_nerf.py:297-371) as one C call.  `precision_fine` (default: the
     same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it."""
     lib = _lib.load()
@@ -326,6 +329,8 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
     n, S, Ni = rays.shape[0], t_vals.shape[0], int(n_importance)
     _shape(bc_rgb, "bc_rgb", n, 3)
     _shape(t_rand, "t_rand", n, S)
+    _shape(noise_coarse, "noise_coarse", n, S)
+    _shape(noise_fine, "noise_fine", n, S + Ni)
     _net_buffers(lib, packed_c, folded_c, precision, "_coarse")
     if Ni > 0:
         if u is None or packed_f is None or folded_f is None:
@@ -333,7 +338,7 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
         _u_shape(u, n, Ni)
         _net_buffers(lib, packed_f, folded_f, precision if precision_fine is None else precision_fine, "_fine")
     dev = rays.device
-    with _Launch(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, t_rand) as L:
+    with _Launch(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, t_rand, noise_coarse, noise_fine) as L:
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         out = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n))
         if Ni > 0:
@@ -357,6 +362,8 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
         a.t_vals, a.t_rand = _ptr(t_vals, "t_vals"), _ptr(t_rand, "t_rand")
         a.u = _ptr(u, "u") if u is not None else None
         a.u_per_ray = 1 if (u is not None and u.dim() == 2) else 0
+        a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
+        a.noise_coarse, a.noise_fine = _ptr(noise_coarse, "noise_coarse"), _ptr(noise_fine, "noise_fine")
         for k, v in out.items():
             setattr(a, k, v.data_ptr())
         nbytes = lib.idealnerf_render_workspace_bytes(n, S, Ni)

@@ -131,10 +131,11 @@ int idealnerf_query_points_fwd(const float* packed, const float* folded, int pre
 int idealnerf_frame_rays(const float* c2w, int H, int W, float focal, float cx, float cy, float near_, float far_,
                          int row0, int nrows, float* rays_out, void* stream);
 
-/* Coarse depths (audio_exp_nerf.py:306-330): z[r,s] = near_r (1-t_s) + far_r t_s, with
+/* Coarse depths (audio_exp_nerf.py:306-330): z[r,s] = near_r (1-t_s) + far_r t_s -- or, with
+ * lindisp != 0, linear in inverse depth: 1 / ((1/near_r)(1-t_s) + (1/far_r) t_s) (:309-310) -- with
  * optional stratified jitter from t_rand[n_rays, n_samples] (NULL = perturb 0).
  * t_vals[n_samples] is the caller's torch.linspace(0,1,S) buffer. */
-int idealnerf_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays,
+int idealnerf_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int lindisp, int64_t n_rays,
                             int n_samples, float* z, void* stream);
 
 /*
@@ -151,8 +152,12 @@ typedef struct idn_composite_out {
     float* last_weight; /* [n] = weights[:, -1] */
 } idn_composite_out;
 
+/* sigma_noise[n_rays, n_samples] (may be NULL) is added to the raw density before its ReLU: the caller draws
+ * it as the reference does, randn * raw_noise_std (baseline.py:353-361).  white_bkgd != 0 adds 1 - acc_map to
+ * rgb_map (:372-373).  The reference's Network never enables either (audio_exp_nerf.py:297-299). */
 int idealnerf_composite_fwd(const float* raw, const float* z, const float* rays, const float* bc_rgb,
-                            int64_t n_rays, int n_samples, const idn_composite_out* out, void* stream);
+                            const float* sigma_noise, int white_bkgd, int64_t n_rays, int n_samples,
+                            const idn_composite_out* out, void* stream);
 
 /*
  * sample_pdf + merge (helper.py:269-313, audio_exp_nerf.py:340-349).
@@ -222,6 +227,11 @@ typedef struct idn_render_args {
      * exact; the fine pass (3/4 of the samples, nothing sampled after it) runs at the bf16 matrix rate.
      * packed_fine must have been packed for that arithmetic. */
     int precision_fine_plus1;
+    /* render_rays' remaining switches (audio_exp_nerf.py:297-299; the reference leaves them at their defaults) */
+    int lindisp;               /* coarse depths linear in inverse depth */
+    int white_bkgd;            /* rgb += 1 - acc, in both passes */
+    const float* noise_coarse; /* [n, n_samples] or NULL: raw_noise_std noise of the coarse pass, drawn by the caller */
+    const float* noise_fine;   /* [n, n_samples + n_importance] or NULL */
 } idn_render_args;
 
 size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);

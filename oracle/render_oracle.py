@@ -192,7 +192,7 @@ def facenerf_forward(p: Params, x: torch.Tensor, aud: Optional[torch.Tensor],
 #     (+ rgb_map_fg variant           NeRFs/TorsoNeRF/run_nerf.py:715-766)
 # --------------------------------------------------------------------------
 def composite(raw: torch.Tensor, z: torch.Tensor, rays_d: torch.Tensor, bc_rgb: torch.Tensor,
-              with_fg: bool = False):
+              with_fg: bool = False, sigma_noise: Optional[torch.Tensor] = None, white_bkgd: bool = False):
     """raw[n,S,4], z[n,S], d[n,3], bc[n,3] -> rgb_map, disp, acc, weights, depth (, rgb_fg).
 
     dists = [dz, 1e10] * |d| (baseline.py:345-349); colours sigmoid(raw_rgb) with
@@ -201,7 +201,9 @@ def composite(raw: torch.Tensor, z: torch.Tensor, rays_d: torch.Tensor, bc_rgb: 
     T_s = prod_{t<s}(1 - alpha_t + 1e-10) (:365-367); w = alpha*T;
     rgb = sum w c (:368); depth = sum w z (:370); disp = 1/max(1e-10, depth/sum w)
     (:371); acc = sum w (:372).  Torso variant: rgb_fg = sum_{s<S-1} w c
-    (TorsoNeRF/run_nerf.py:757).
+    (TorsoNeRF/run_nerf.py:757).  ``sigma_noise`` [n,S] is added to the density before its
+    ReLU (the caller draws it: randn * raw_noise_std, baseline.py:353-361); ``white_bkgd`` adds
+    1 - acc to the colour (:372-373).
     """
     n = z.shape[0]
     dz = z[..., 1:] - z[..., :-1]
@@ -209,7 +211,8 @@ def composite(raw: torch.Tensor, z: torch.Tensor, rays_d: torch.Tensor, bc_rgb: 
     dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
     rgb = torch.sigmoid(raw[..., :3])
     rgb = torch.cat([rgb[:, :-1, :], bc_rgb[:, None, :]], dim=1)
-    alpha = 1.0 - torch.exp(-(torch.relu(raw[..., 3]) + 1e-6) * dists)
+    sigma = raw[..., 3] if sigma_noise is None else raw[..., 3] + sigma_noise
+    alpha = 1.0 - torch.exp(-(torch.relu(sigma) + 1e-6) * dists)
     trans = torch.cumprod(torch.cat([torch.ones((n, 1)), 1.0 - alpha + 1e-10], dim=-1), dim=-1)[:, :-1]
     weights = alpha * trans
     rgb_map = torch.sum(weights[..., None] * rgb, dim=-2)
@@ -217,6 +220,8 @@ def composite(raw: torch.Tensor, z: torch.Tensor, rays_d: torch.Tensor, bc_rgb: 
     wsum = torch.sum(weights, dim=-1)
     disp = 1.0 / torch.max(1e-10 * torch.ones_like(depth), depth / wsum)
     acc = torch.sum(weights, dim=-1)
+    if white_bkgd:
+        rgb_map = rgb_map + (1.0 - acc[..., None])
     if with_fg:
         rgb_fg = torch.sum(weights[:, :-1, None] * rgb[:, :-1, :], dim=-2)
         return rgb_map, disp, acc, weights, depth, rgb_fg
@@ -281,13 +286,17 @@ def sample_importance(bins: torch.Tensor, weights_inner: torch.Tensor, n_importa
 # a3/a4/a8/a9  render_rays            NeRFs/HeadNeRF/train/audio_exp_nerf.py:297-394
 # --------------------------------------------------------------------------
 def coarse_depths(near: torch.Tensor, far: torch.Tensor, n_samples: int,
-                  t_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """near,far [n,1] -> z[n,S]: z = near(1-t)+far t, t = linspace(0,1,S)
+                  t_rand: Optional[torch.Tensor] = None, lindisp: bool = False) -> torch.Tensor:
+    """near,far [n,1] -> z[n,S]: z = near(1-t)+far t, t = linspace(0,1,S), or with
+    ``lindisp`` linear in inverse depth, z = 1/((1/near)(1-t) + (1/far) t)
     (audio_exp_nerf.py:306-312); if ``t_rand`` [n,S] is given, stratified
     jitter z = lower + (upper-lower)*t_rand with t_rand[:, -1] forced to 1
     (:314-330)."""
-    t = torch.linspace(0.0, 1.0, steps=n_samples)
-    z = near * (1.0 - t) + far * t
+    t = torch.linspace(0.0, 1.0, steps=n_samples, dtype=near.dtype)
+    if lindisp:
+        z = 1.0 / (1.0 / near * (1.0 - t) + 1.0 / far * t)
+    else:
+        z = near * (1.0 - t) + far * t
     z = z.expand(near.shape[0], n_samples)
     if t_rand is not None:
         mids = 0.5 * (z[..., 1:] + z[..., :-1])
@@ -316,7 +325,9 @@ def _query(p: Params, pts: torch.Tensor, viewdirs: torch.Tensor, aud, expr, late
 def render_rays(rays: torch.Tensor, bc_rgb: torch.Tensor, coarse: Params, fine: Optional[Params],
                 aud, expr, latent, n_samples: int = 64, n_importance: int = 128,
                 dims=None, t_rand: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None,
-                with_fg: bool = False, taps: bool = False) -> Dict[str, torch.Tensor]:
+                with_fg: bool = False, taps: bool = False, lindisp: bool = False, white_bkgd: bool = False,
+                noise_coarse: Optional[torch.Tensor] = None,
+                noise_fine: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """rays[n,11], bc_rgb[n,3] -> dict with the reference's keys
     (audio_exp_nerf.py:297-371): rgb_map, disp_map, acc_map, and when
     n_importance>0: rgb0, disp0, acc0, z_std (population std of the importance
@@ -328,10 +339,10 @@ def render_rays(rays: torch.Tensor, bc_rgb: torch.Tensor, coarse: Params, fine: 
     o, d = rays[:, 0:3], rays[:, 3:6]
     view = rays[:, -3:]
     near, far = rays[:, 6:7], rays[:, 7:8]
-    z = coarse_depths(near, far, n_samples, t_rand)
+    z = coarse_depths(near, far, n_samples, t_rand, lindisp=lindisp)
     pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
     raw = _query(coarse, pts, view, aud, expr, latent, dims)
-    comp = composite(raw, z, d, bc_rgb, with_fg=with_fg)
+    comp = composite(raw, z, d, bc_rgb, with_fg=with_fg, sigma_noise=noise_coarse, white_bkgd=white_bkgd)
     rgb_map, disp, acc, weights, depth = comp[:5]
     out = {}
     tap = {}
@@ -349,7 +360,7 @@ def render_rays(rays: torch.Tensor, bc_rgb: torch.Tensor, coarse: Params, fine: 
         z, _ = torch.sort(torch.cat([z, z_s], dim=-1), dim=-1)
         pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
         raw = _query(fine, pts, view, aud, expr, latent, dims)
-        comp = composite(raw, z, d, bc_rgb, with_fg=with_fg)
+        comp = composite(raw, z, d, bc_rgb, with_fg=with_fg, sigma_noise=noise_fine, white_bkgd=white_bkgd)
         rgb_map, disp, acc, weights, depth = comp[:5]
         out["z_std"] = torch.std(z_s, dim=-1, unbiased=False)
         out["last_weight"] = weights[..., -1]

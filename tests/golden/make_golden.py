@@ -487,8 +487,72 @@ def golden_torso():
     print("wrote torso_signal.npz", et_batch.shape, torch.stack(signals, 0).shape)
 
 
+def golden_flags():
+    """`python make_golden.py flags`: the three switches the reference's Network leaves at their defaults
+    (audio_exp_nerf.py:297-299) -- lindisp (:309-310), white_bkgd and raw_noise_std (baseline.py:353-373) --
+    from the reference's own raw2outputs and render_rays on 64 rays of the 32x32 golden frame."""
+    install_shims()
+    sys.argv = [sys.argv[0], "--perturb", "0", "--dim_aud", "64", "--dim_expr", "76",
+                "--N_samples", "64", "--N_importance", "128", "--near", str(NEAR), "--far", str(FAR),
+                "--vis_path", "/tmp/idealnerf_golden_vis", "--chunk", "512"]
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    import oracle
+    import NeRFs.HeadNeRF.helper as helper
+    from NeRFs.HeadNeRF.train import baseline
+    from NeRFs.HeadNeRF.train import audio_exp_nerf as aen
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    fx = {}
+    # raw2outputs on the S=64 inputs of raw2outputs.npz
+    g = dict(np.load(os.path.join(HERE, "raw2outputs.npz")))
+    raw, z, d, bc = (f32(g["s64_" + k]) for k in ("raw", "z", "d", "bc"))
+    with torch.no_grad():
+        for tag, kw in (("white", dict(white_bkgd=True)), ("noise", dict(raw_noise_std=0.7, pytest=True)),
+                        ("both", dict(raw_noise_std=2.5, white_bkgd=True, pytest=True))):
+            rgb_map, disp, acc, w, depth = baseline.raw2outputs(raw, z, d, bc, **kw)
+            fx.update({f"r2o_{tag}_rgb_map": rgb_map.numpy(), f"r2o_{tag}_disp": disp.numpy(), f"r2o_{tag}_acc": acc.numpy(),
+                       f"r2o_{tag}_weights": w.numpy(), f"r2o_{tag}_depth": depth.numpy()})
+    # render_rays on 64 rays of the golden frame
+    dims = oracle.facenerf_dims()
+    H = W = 32
+    syn = oracle.synthetic_frame(H, W, seed=0, dims=dims)
+    net = aen.Network(H, W, syn["focal"], NEAR, FAR, 512, None, 64, 128)
+    load_state(net.face_nerf_coarse, scale_sigma(oracle.xavier_facenerf_params(2, dims), 300.0, 0.3))
+    load_state(net.face_nerf_fine, scale_sigma(oracle.xavier_facenerf_params(3, dims), 300.0, 0.3))
+    net.eval()
+    f = dict(np.load(os.path.join(HERE, "frame32.npz")))
+    rays = f32(f["rays"])
+    sel = torch.from_numpy(np.random.RandomState(99).choice(H * W, size=64, replace=False))
+    fx["sel"] = sel.numpy()
+    z_tap = {}
+    real_r2o = aen.raw2outputs
+
+    def tap(raw_, z_vals, *a, **k):
+        z_tap.setdefault("coarse" if raw_.shape[1] == 64 else "fine", z_vals.detach().clone())
+        return real_r2o(raw_, z_vals, *a, **k)
+
+    aen.raw2outputs = tap
+    try:
+        with torch.no_grad():
+            for tag, kw in (("lindisp", dict(lindisp=True)), ("white", dict(white_bkgd=True)),
+                            ("noise", dict(raw_noise_std=0.5, pytest=True, perturb=0.0))):
+                z_tap.clear()
+                ret = net.render_rays(rays[sel], syn["bc"].reshape(-1, 3)[sel], syn["aud"], syn["c2w"], syn["latent"],
+                                      syn["expr"], **kw)
+                fx.update({f"rr_{tag}_{k}": v.numpy() for k, v in ret.items()})
+                fx[f"rr_{tag}_z_coarse"] = z_tap["coarse"].numpy()
+    finally:
+        aen.raw2outputs = real_r2o
+    np.savez_compressed(os.path.join(HERE, "flags.npz"), **fx)
+    print("wrote flags.npz:", sorted(fx)[:6], "...", len(fx), "arrays")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "agg":
+    if len(sys.argv) > 1 and sys.argv[1] == "flags":
+        golden_flags()
+    elif len(sys.argv) > 1 and sys.argv[1] == "agg":
         golden_agg()
     elif len(sys.argv) > 1 and sys.argv[1] == "torso":
         golden_torso()

@@ -105,10 +105,6 @@ def test_helper_raw2outputs_golden(idn, dev, golden, frame_net, S):
         for got, name in ((rgb_map, "rgb_map"), (disp_map, "disp"), (acc_map, "acc"), (weights, "weights"),
                           (depth_map, "depth")):
             assert rel_err(got, g[f"s{S}_{name}"]) < 2e-6, name
-    with pytest.raises(NotImplementedError):
-        helper.raw2outputs(k("raw"), k("z"), k("d"), k("bc"), raw_noise_std=1.0)
-    with pytest.raises(NotImplementedError):
-        helper.raw2outputs(k("raw"), k("z"), k("d"), k("bc"), white_bkgd=True)
 
 
 # --------------------------------------------------------------------------- helper.get_rays
@@ -289,3 +285,40 @@ def test_launch_follows_the_tensors_device_and_stream(idn, dev):
         out = ops.composite_fwd(raw2, z, rays, bc)["rgb_map"]   # ... and consumed there without a sync in between
     side.synchronize()
     assert torch.equal(out, ref)
+
+
+# --------------------------------------------------------------------------- lindisp / white_bkgd / raw_noise_std
+def test_render_switches_golden(idn, dev, golden, frame_net):
+    """The three switches the reference's Network leaves at their defaults (audio_exp_nerf.py:297-299): through
+    helper.raw2outputs and through Network.render_rays, against the reference's own outputs."""
+    from idealnerf_amd import helper
+    g, r, f = golden("flags"), golden("raw2outputs"), golden("frame32")
+    k = lambda n: T(r["s64_" + n]).to(dev)
+    for tag, kw in (("white", dict(white_bkgd=True)), ("noise", dict(raw_noise_std=0.7, pytest=True)),
+                    ("both", dict(raw_noise_std=2.5, white_bkgd=True, pytest=True))):
+        out = helper.raw2outputs(k("raw"), k("z"), k("d"), k("bc"), **kw)
+        for got, name in zip(out, ("rgb_map", "disp", "acc", "weights", "depth")):
+            assert rel_err(got, g[f"r2o_{tag}_{name}"]) < 2e-6, (tag, name)
+    net, syn = frame_net
+    sel = T(g["sel"])
+    rays, bc = T(f["rays"])[sel].to(dev), syn["bc"].reshape(-1, 3)[sel].to(dev)
+    args = (syn["aud"].to(dev), syn["c2w"], syn["latent"].to(dev), syn["expr"].to(dev))
+    with torch.no_grad():
+        for tag, kw in (("lindisp", dict(lindisp=True)), ("white", dict(white_bkgd=True)),
+                        ("noise", dict(raw_noise_std=0.5, pytest=True, perturb=0.0))):
+            out = net.render_rays(rays, bc, *args, taps=True, **kw)
+            for key in ("rgb_map", "rgb0", "disp_map", "acc_map", "disp0", "acc0"):
+                assert rel_err(out[key], g[f"rr_{tag}_{key}"]) < RGB_TOL, (tag, key)
+            assert abs_err(out["last_weight"], g[f"rr_{tag}_last_weight"]) < W_TOL
+            assert rel_err(out["tap_z_coarse"], g[f"rr_{tag}_z_coarse"]) < 2e-7, tag
+    np.testing.assert_array_equal(net.render_rays(rays, bc, *args, taps=True)["tap_z_coarse"].cpu().numpy(),
+                                  g["rr_white_z_coarse"])
+    # the training path takes lindisp (depths carry no gradient) and refuses the two compositing switches
+    net.train()
+    try:
+        with pytest.raises(NotImplementedError):
+            net.render_rays(rays, bc, *args, white_bkgd=True)
+        out = net.render_rays(rays, bc, *args, lindisp=True, perturb=0.0)
+        assert rel_err(out["rgb_map"], g["rr_lindisp_rgb_map"]) < RGB_TOL and out["rgb_map"].requires_grad
+    finally:
+        net.eval()

@@ -177,3 +177,22 @@ def test_torso_conditioning_golden(golden):
     # the product's host-side restatement of the same three lines, on CPU tensors (plain torch math)
     from idealnerf_amd.train_torso import pose_to_euler_trans
     np.testing.assert_array_equal(pose_to_euler_trans(poses).numpy(), g["euler_trans"])
+
+
+def test_render_switches_golden(golden):
+    """lindisp / white_bkgd / raw_noise_std (the switches the reference's Network leaves at their defaults,
+    audio_exp_nerf.py:297-299,309-310; baseline.py:353-373) in the oracle against the reference's own outputs."""
+    g, r = golden("flags"), golden("raw2outputs")
+    f32 = lambda k: torch.from_numpy(r["s64_" + k])
+    raw, z, d, bc = f32("raw"), f32("z"), f32("d"), f32("bc")
+    np.random.seed(0)
+    u07 = torch.Tensor(np.random.rand(64, 64) * 0.7)
+    np.random.seed(0)
+    u25 = torch.Tensor(np.random.rand(64, 64) * 2.5)
+    for tag, kw in (("white", dict(white_bkgd=True)), ("noise", dict(sigma_noise=u07)), ("both", dict(sigma_noise=u25, white_bkgd=True))):
+        out = oracle.composite(raw, z, d, bc, **kw)
+        for got, name in zip(out, ("rgb_map", "disp", "acc", "weights", "depth")):
+            np.testing.assert_array_equal(got.numpy(), g[f"r2o_{tag}_{name}"], err_msg=f"{tag} {name}")
+    near = torch.full((4, 1), 0.5772005200386048)
+    far = torch.full((4, 1), 1.1772005200386046)
+    np.testing.assert_array_equal(oracle.coarse_depths(near, far, 64, lindisp=True).numpy(), g["rr_lindisp_z_coarse"][:4])
