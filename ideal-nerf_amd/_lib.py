@@ -63,6 +63,8 @@ PROTOTYPES = {
     "idealnerf_coarse_depths": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, fp, fp]),
     "idealnerf_composite_fwd": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.POINTER(CompositeOut), fp]),
     "idealnerf_sample_pdf_fwd": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp]),
+    "idealnerf_march_fwd": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, fp, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                      C.POINTER(CompositeOut), fp, fp, fp, fp, fp, fp]),
     "idealnerf_sample_pdf_bins_fwd": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp, fp]),
     "idealnerf_invert_cdf": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp]),
     "idealnerf_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

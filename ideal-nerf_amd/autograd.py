@@ -100,7 +100,10 @@ class RenderRaysFn(torch.autograd.Function):
         fc = coarse.folded_bias(aud_d, expr_d, lat_d)
         z_c = ops.coarse_depths(rays, linspace01(S, dev), t_rand, lindisp=lindisp)
         raw_c, acts_c = _train_query(coarse, fc, rays, z_c)
-        comp_c = ops.composite_fwd(raw_c, z_c, rays, bc, with_fg=with_fg, with_weights=Ni > 0)
+        if Ni > 0:   # coarse compositing + importance sampling + merge: one kernel, the weights stay on chip
+            comp_c = smp = ops.march_fwd(raw_c, z_c, rays, bc, u, Ni, with_fg=with_fg)
+        else:
+            comp_c = ops.composite_fwd(raw_c, z_c, rays, bc, with_fg=with_fg, with_weights=False)
         ctx.nets, ctx.Ni, ctx.with_fg = (coarse, fine), Ni, with_fg
         ctx.cond = (aud_d, expr_d, lat_d)
         ctx.needs = (aud is not None and aud.requires_grad, latent is not None and latent.requires_grad)
@@ -112,7 +115,6 @@ class RenderRaysFn(torch.autograd.Function):
             ctx.mark_non_differentiable(outs[1])
             return tuple(outs)
         ff = fine.folded_bias(aud_d, expr_d, lat_d)
-        smp = ops.sample_pdf_fwd(z_c, comp_c["weights"], u, Ni)
         z_f = smp["z_fine"]
         raw_f, acts_f = _train_query(fine, ff, rays, z_f)
         comp_f = ops.composite_fwd(raw_f, z_f, rays, bc, with_fg=with_fg, with_weights=False)

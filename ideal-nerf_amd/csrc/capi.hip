@@ -187,6 +187,17 @@ int idealnerf_sample_pdf_fwd(const float* z, const float* weights, const float* 
                              inds, cdf, z_fine, z_std, (hipStream_t)stream);
 }
 
+int idealnerf_march_fwd(const float* raw, const float* z, const float* rays, const float* bc_rgb, const float* sigma_noise,
+                        int white_bkgd, const float* u, int u_per_ray, int64_t n_rays, int n_samples, int n_importance,
+                        const idn_composite_out* out, float* z_samples, int64_t* inds, float* cdf, float* z_fine,
+                        float* z_std, void* stream) {
+    if (n_rays < 0) return fail(IDN_EINVAL, "n_rays < 0");
+    if (n_rays == 0) return IDN_OK;
+    if (!raw || !z || !rays || !bc_rgb || !u || !out) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_march(raw, z, rays, bc_rgb, sigma_noise, white_bkgd, *out, u, u_per_ray, n_rays, n_samples, n_importance,
+                        z_samples, inds, cdf, z_fine, z_std, (hipStream_t)stream);
+}
+
 int idealnerf_sample_pdf_bins_fwd(const float* bins, const float* weights, const float* u, int u_per_ray,
                                   int64_t n_rays, int n_bins, int n_importance, float* z_samples, int64_t* inds,
                                   float* cdf, void* stream) {
@@ -299,7 +310,7 @@ static const int64_t kRenderChunk = 32768;  // rays per internal pass (bounds th
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RenderWs {
-    float *z_c, *raw_c, *w_c, *z_f, *raw_f, *w_f;
+    float *z_c, *raw_c, *z_f, *raw_f;   // the compositing weights stay on chip (march kernel) or go straight to their tap
     size_t bytes;
 };
 static RenderWs carve(char* base, int64_t n, int S, int Ni) {
@@ -314,10 +325,8 @@ static RenderWs carve(char* base, int64_t n, int S, int Ni) {
     };
     w.z_c = take((size_t)c * S);
     w.raw_c = take((size_t)c * S * 4);
-    w.w_c = take((size_t)c * S);
     w.z_f = take((size_t)c * Sf);
     w.raw_f = take((size_t)c * Sf * 4);
-    w.w_f = take((size_t)c * Sf);
     w.bytes = off;
     return w;
 }
@@ -365,19 +374,20 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
         co.disp_map = off(fine ? a->disp0 : a->disp_map, r0);
         co.acc_map = off(fine ? a->acc0 : a->acc_map, r0);
         co.depth_map = fine ? nullptr : off(a->depth_map, r0);
-        co.weights = w.w_c;
+        co.weights = off(a->tap_weights_coarse, r0 * S);
         co.rgb_fg = off(fine ? a->rgb_fg0 : a->rgb_fg, r0 * 3);
         co.last_weight = off(fine ? a->last_weight0 : a->last_weight, r0);
-        if (int e = launch_composite(w.raw_c, w.z_c, rays, bc, c, S, off(a->noise_coarse, r0 * S), a->white_bkgd, co, st)) return e;
         if (int e = tap(off(a->tap_z_coarse, r0 * S), w.z_c, (size_t)c * S * 4)) return e;
         if (int e = tap(off(a->tap_raw_coarse, r0 * S * 4), w.raw_c, (size_t)c * S * 16)) return e;
-        if (int e = tap(off(a->tap_weights_coarse, r0 * S), w.w_c, (size_t)c * S * 4)) return e;
-        if (!fine) continue;
-
+        if (!fine) {
+            if (int e = launch_composite(w.raw_c, w.z_c, rays, bc, c, S, off(a->noise_coarse, r0 * S), a->white_bkgd, co, st)) return e;
+            continue;
+        }
+        // the march between the passes: coarse compositing, inverse-CDF sampling and the merge in one kernel
         const float* u = a->u_per_ray ? a->u + r0 * Ni : a->u;
-        if (int e = launch_sample_pdf(w.z_c, w.w_c, nullptr, nullptr, u, a->u_per_ray, c, S, Ni,
-                                      off(a->tap_z_samples, r0 * Ni), off(a->tap_inds, r0 * Ni),
-                                      off(a->tap_cdf, r0 * (S - 1)), w.z_f, off(a->z_std, r0), st))
+        if (int e = launch_march(w.raw_c, w.z_c, rays, bc, off(a->noise_coarse, r0 * S), a->white_bkgd, co, u, a->u_per_ray, c, S, Ni,
+                                 off(a->tap_z_samples, r0 * Ni), off(a->tap_inds, r0 * Ni), off(a->tap_cdf, r0 * (S - 1)),
+                                 w.z_f, off(a->z_std, r0), st))
             return e;
         if (int e = launch_mlp(prec_fine, a->packed_fine, a->folded_fine, nullptr, rays, w.z_f, nullptr, nullptr, c * Sf, Sf, w.raw_f, st)) return e;
         idn_composite_out fo = {};
@@ -385,13 +395,12 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
         fo.disp_map = off(a->disp_map, r0);
         fo.acc_map = off(a->acc_map, r0);
         fo.depth_map = off(a->depth_map, r0);
-        fo.weights = a->tap_weights_fine ? w.w_f : nullptr;
+        fo.weights = off(a->tap_weights_fine, r0 * Sf);
         fo.rgb_fg = off(a->rgb_fg, r0 * 3);
         fo.last_weight = off(a->last_weight, r0);
         if (int e = launch_composite(w.raw_f, w.z_f, rays, bc, c, Sf, off(a->noise_fine, r0 * Sf), a->white_bkgd, fo, st)) return e;
         if (int e = tap(off(a->tap_z_fine, r0 * Sf), w.z_f, (size_t)c * Sf * 4)) return e;
         if (int e = tap(off(a->tap_raw_fine, r0 * Sf * 4), w.raw_f, (size_t)c * Sf * 16)) return e;
-        if (int e = tap(off(a->tap_weights_fine, r0 * Sf), w.w_f, (size_t)c * Sf * 4)) return e;
     }
     return IDN_OK;
 }

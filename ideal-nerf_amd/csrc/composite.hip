@@ -161,13 +161,11 @@ int launch_to8b(const float* rgb, int64_t n_pixels, int swap_rb, unsigned char* 
 // Lane l owns samples l*SPL .. l*SPL+SPL-1 (contiguous, so a ray's prefix product is a
 // lane-local product followed by one wave scan).
 // ---------------------------------------------------------------------------
+// One ray per wave.  wout[i] = weight of sample lane * SPL + i (0 beyond S), for a caller that goes on with them.
 template <int SPL>
-__global__ __launch_bounds__(256) void composite_kernel(const float4* raw, const float* z, const float* rays,
-                                                        const float* bc, long n_rays, int S, const float* noise,
-                                                        int white_bkgd, idn_composite_out out) {
-    const int lane = threadIdx.x & 63;
-    const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= n_rays) return;  // wave-uniform
+__device__ __forceinline__ void composite_ray(const float4* raw, const float* z, const float* rays, const float* bc,
+                                              long ray, int lane, int S, const float* noise, int white_bkgd,
+                                              const idn_composite_out& out, float (&wout)[SPL]) {
     const float* rr = rays + ray * IDN_RAY_FLOATS;
     const float dn = sqrtf((rr[3] * rr[3] + rr[4] * rr[4]) + rr[5] * rr[5]);  // torch.norm(rays_d)
     const float4* rawr = raw + ray * S;
@@ -209,6 +207,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* raw, const
         const float T = (float)run;  // cumprod output, rounded to fp32 per element
         const float w = alpha[i] * T;
         run *= (double)tf[i];
+        wout[i] = (s < S) ? w : 0.0f;
         if (s < S) {
             float cr, cg, cb;
             if (s == S - 1) {  // last sample's colour := background pixel (baseline.py:352)
@@ -258,6 +257,17 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* raw, const
         if (out.acc_map) out.acc_map[ray] = acc;
         if (out.disp_map) out.disp_map[ray] = 1.0f / fmaxf(1e-10f, depth / acc);
     }
+}
+
+template <int SPL>
+__global__ __launch_bounds__(256) void composite_kernel(const float4* raw, const float* z, const float* rays,
+                                                        const float* bc, long n_rays, int S, const float* noise,
+                                                        int white_bkgd, idn_composite_out out) {
+    const int lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;  // wave-uniform
+    float w[SPL];
+    composite_ray<SPL>(raw, z, rays, bc, ray, lane, S, noise, white_bkgd, out, w);
 }
 
 int launch_composite(const float* raw, const float* z, const float* rays, const float* bc, int64_t n_rays, int S,
@@ -354,16 +364,10 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes of this wave are done
 }
 
-__global__ __launch_bounds__(256) void sample_pdf_kernel(SampleArgs a) {
-    __shared__ float s_cdf[4][kMaxBins];
-    __shared__ float s_bins[4][kMaxBins];
-    __shared__ float s_val[4][kMaxFine];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long ray = (long)blockIdx.x * 4 + wv;
-    if (ray >= a.n_rays) return;  // wave-uniform; no block-level barrier below
-    float* cdf = s_cdf[wv];
-    float* bins = s_bins[wv];
-    float* val = s_val[wv];
+// One ray per wave; cdf / bins / val are this wave's LDS rows.  `w_lds` (optional): the ray's S compositing
+// weights already in LDS (the fused march kernel), instead of a.weights in global memory.
+__device__ __forceinline__ void sample_pdf_ray(const SampleArgs& a, long ray, int lane, float* cdf, float* bins, float* val,
+                                               const float* w_lds) {
     const int nb = a.nb;
 
     if (a.cdf_in) {
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SampleArgs a) {
         } else {          // bins = z midpoints; weights[:, 1:-1] (audio_exp_nerf.py:340-342)
             const float* zr = a.z + ray * a.S;
             for (int k = lane; k < nb; k += 64) bins[k] = 0.5f * (zr[k + 1] + zr[k]);
-            wr = a.weights + ray * a.S + 1;
+            wr = (w_lds ? w_lds : a.weights + ray * a.S) + 1;
         }
         // w' = w + 1e-5; lane l owns pdf entries l*4 .. l*4+3
         float wp[4];
@@ -500,6 +504,63 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SampleArgs a) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(SampleArgs a) {
+    __shared__ float s_cdf[4][kMaxBins];
+    __shared__ float s_bins[4][kMaxBins];
+    __shared__ float s_val[4][kMaxFine];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long ray = (long)blockIdx.x * 4 + wv;
+    if (ray >= a.n_rays) return;  // wave-uniform; no block-level barrier below
+    sample_pdf_ray(a, ray, lane, s_cdf[wv], s_bins[wv], s_val[wv], nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// The ray march between the two network passes as ONE kernel (audio_exp_nerf.py:335-349): coarse
+// raw2outputs, sample_pdf and the sorted merge, one wave per ray.  The compositing weights go from the
+// lanes' registers into the wave's LDS row and the pdf / cdf / inversion / merge run on them there: the
+// [n, S] weight matrix never exists in HBM (unless its debug tap is asked for), and the coarse pass of a
+// render is MLP -> march -> MLP -> composite.
+// ---------------------------------------------------------------------------
+template <int SPL>
+__global__ __launch_bounds__(256) void march_kernel(const float4* raw, const float* rays, const float* bc, const float* noise,
+                                                    int white_bkgd, idn_composite_out out, SampleArgs a) {
+    __shared__ float s_cdf[4][kMaxBins];
+    __shared__ float s_bins[4][kMaxBins];
+    __shared__ float s_val[4][kMaxFine];
+    __shared__ float s_w[4][kMaxBins + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long ray = (long)blockIdx.x * 4 + wv;
+    if (ray >= a.n_rays) return;  // wave-uniform; no block-level barrier below
+    float w[SPL];
+    composite_ray<SPL>(raw, a.z, rays, bc, ray, lane, a.S, noise, white_bkgd, out, w);
+#pragma unroll
+    for (int i = 0; i < SPL; ++i)
+        if (lane * SPL + i < a.S) s_w[wv][lane * SPL + i] = w[i];
+    wave_lds_fence();
+    sample_pdf_ray(a, ray, lane, s_cdf[wv], s_bins[wv], s_val[wv], s_w[wv]);
+}
+
+int launch_march(const float* raw, const float* z, const float* rays, const float* bc, const float* noise, int white_bkgd,
+                 const idn_composite_out& out, const float* u, int u_per_ray, int64_t n_rays, int S, int Ni,
+                 float* z_samples, int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s) {
+    if (n_rays <= 0) return IDN_OK;
+    const int nb = S - 1;
+    if (S < 3 || S > 64 * kMaxSpl || nb > kMaxBins - 1) return fail(IDN_EUNSUPPORTED, "march: n_samples %d outside [3, %d]", S, kMaxBins);
+    if (Ni < 1 || Ni > kMaxNi) return fail(IDN_EUNSUPPORTED, "march: n_importance %d outside [1, %d]", Ni, kMaxNi);
+    if (S + Ni > kMaxFine) return fail(IDN_EUNSUPPORTED, "march: n_samples + n_importance > %d", kMaxFine);
+    SampleArgs a{z, nullptr, nullptr, nullptr, u, u_per_ray, (long)n_rays, S, Ni, nb, z_samples, inds, cdf_out, z_fine, z_std};
+    const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
+    const float4* r4 = reinterpret_cast<const float4*>(raw);
+    switch ((S + 63) / 64) {
+        case 1: hipLaunchKernelGGL(march_kernel<1>, grid, block, 0, s, r4, rays, bc, noise, white_bkgd, out, a); break;
+        case 2: hipLaunchKernelGGL(march_kernel<2>, grid, block, 0, s, r4, rays, bc, noise, white_bkgd, out, a); break;
+        case 3: hipLaunchKernelGGL(march_kernel<3>, grid, block, 0, s, r4, rays, bc, noise, white_bkgd, out, a); break;
+        default: hipLaunchKernelGGL(march_kernel<4>, grid, block, 0, s, r4, rays, bc, noise, white_bkgd, out, a); break;
+    }
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
 }
 
 int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in, const float* bins_in,

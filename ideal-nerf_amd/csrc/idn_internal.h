@@ -188,6 +188,10 @@ int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_
                          int lindisp, float* z, hipStream_t s);
 int launch_composite(const float* raw, const float* z, const float* rays, const float* bc, int64_t n_rays, int S,
                      const float* noise, int white_bkgd, const idn_composite_out& out, hipStream_t s);
+// coarse raw2outputs + sample_pdf + merge in one kernel (the weights stay on chip)
+int launch_march(const float* raw, const float* z, const float* rays, const float* bc, const float* noise, int white_bkgd,
+                 const idn_composite_out& out, const float* u, int u_per_ray, int64_t n_rays, int S, int Ni,
+                 float* z_samples, int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s);
 int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in, const float* bins_in,
                       const float* u, int u_per_ray, int64_t n_rays, int S, int Ni, float* z_samples,
                       int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s);

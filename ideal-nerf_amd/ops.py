@@ -269,6 +269,36 @@ def sample_pdf_fwd(z, weights, u, n_importance) -> Dict[str, torch.Tensor]:
     return o
 
 
+def march_fwd(raw, z, rays, bc_rgb, u, n_importance, with_fg=False, with_weights=False, sigma_noise=None,
+              white_bkgd=False) -> Dict[str, torch.Tensor]:
+    """Coarse raw2outputs + sample_pdf + merge as one kernel (audio_exp_nerf.py:335-349): the union of
+    composite_fwd's and sample_pdf_fwd's outputs; `weights` only when asked for."""
+    lib = _lib.load()
+    _shape(z, "z", None, None)
+    n, S = z.shape
+    _shape(raw, "raw", n, S, 4)
+    _shape(rays, "rays", n, RAY_FLOATS)
+    _shape(bc_rgb, "bc_rgb", n, 3)
+    _shape(sigma_noise, "sigma_noise", n, S)
+    per_ray = _u_shape(u, n, n_importance)
+    dev = z.device
+    with _Launch(raw, z, rays, bc_rgb, u, sigma_noise) as L:
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        o = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n), depth_map=new(n), last_weight=new(n))
+        if with_weights:
+            o["weights"] = new(n, S)
+        if with_fg:
+            o["rgb_fg"] = new(n, 3)
+        co = _lib.CompositeOut(**{k: v.data_ptr() for k, v in o.items()})
+        o.update(z_samples=new(n, n_importance), inds=torch.empty((n, n_importance), dtype=torch.int64, device=dev),
+                 cdf=new(n, S - 1), z_fine=new(n, S + n_importance), z_std=new(n))
+        check(lib.idealnerf_march_fwd(_ptr(raw, "raw"), _ptr(z, "z"), _ptr(rays, "rays"), _ptr(bc_rgb, "bc_rgb"),
+                                      _ptr(sigma_noise, "sigma_noise"), int(bool(white_bkgd)), _ptr(u, "u"), per_ray, n, S,
+                                      n_importance, C.byref(co), o["z_samples"].data_ptr(), o["inds"].data_ptr(),
+                                      o["cdf"].data_ptr(), o["z_fine"].data_ptr(), o["z_std"].data_ptr(), L.stream))
+    return o
+
+
 def sample_pdf_bins_fwd(bins, weights, u) -> Dict[str, torch.Tensor]:
     """helper.sample_pdf's own argument list (helper.py:269): bins [n, nb], weights [n, nb-1] (already
     the interior weights), u [Ni] or [n, Ni] -> z_samples, inds, cdf -- pdf, cdf and inversion all by

@@ -175,6 +175,18 @@ int idealnerf_sample_pdf_fwd(const float* z, const float* weights, const float* 
                              int64_t n_rays, int n_samples, int n_importance, float* z_samples, int64_t* inds,
                              float* cdf, float* z_fine, float* z_std, void* stream);
 
+/*
+ * The ray march between the two network passes as one kernel (audio_exp_nerf.py:335-349): raw2outputs of the
+ * coarse pass, sample_pdf on its weights and the sorted merge with the coarse depths, one wavefront per ray.
+ * Same arithmetic and outputs as idealnerf_composite_fwd followed by idealnerf_sample_pdf_fwd (bit for bit),
+ * but the [n, S] weight matrix stays in LDS: out->weights is written only if it is not NULL.
+ * idealnerf_render_rays_fwd uses it for every render with n_importance > 0.
+ */
+int idealnerf_march_fwd(const float* raw, const float* z, const float* rays, const float* bc_rgb, const float* sigma_noise,
+                        int white_bkgd, const float* u, int u_per_ray, int64_t n_rays, int n_samples, int n_importance,
+                        const idn_composite_out* out, float* z_samples, int64_t* inds, float* cdf, float* z_fine,
+                        float* z_std, void* stream);
+
 /* helper.sample_pdf with its own argument list (NeRFs/HeadNeRF/helper.py:269-313): bins[n, n_bins],
  * weights[n, n_bins-1] (the interior weights as the caller sliced them, before the +1e-5), u as above
  * -> z_samples[n, Ni], inds[n, Ni], cdf[n, n_bins] (each may be NULL).  Same kernel, same pdf / cdf

@@ -301,6 +301,34 @@ def test_sample_pdf_row_sum_follows_aten_order(idn, dev, K):
     np.testing.assert_array_equal(o["z_samples"].cpu().numpy(), zs_ref.numpy())
 
 
+@pytest.mark.parametrize("S,Ni", [(64, 128), (3, 1), (65, 64), (130, 200), (256, 256)])
+def test_march_equals_composite_then_sample_pdf(idn, dev, S, Ni):
+    """The fused march kernel (coarse raw2outputs + sample_pdf + merge, weights kept in LDS) against the two
+    separate launches it replaces: every output bit for bit, deterministic and random u, with and without the
+    weight tap, ragged ray counts."""
+    rs = np.random.RandomState(S + Ni)
+    n = 1027
+    raw = T(rs.standard_normal((n, S, 4)).astype(np.float32))
+    raw[..., 3] *= 30.0
+    z = torch.sort(T(rs.uniform(NEAR, FAR, size=(n, S)).astype(np.float32)), dim=-1)[0]
+    rays = torch.zeros((n, 11))
+    rays[:, 3:6] = T(rs.standard_normal((n, 3)).astype(np.float32))
+    bc = T(rs.uniform(0, 1, size=(n, 3)).astype(np.float32))
+    noise = T((rs.uniform(0, 1, size=(n, S)) * 0.3).astype(np.float32))
+    g = lambda t: t.to(dev)
+    for u in (torch.linspace(0.0, 1.0, Ni), T(rs.uniform(0, 1, size=(n, Ni)).astype(np.float32))):
+        for kw in (dict(), dict(sigma_noise=g(noise), white_bkgd=True)):
+            a = idn.ops.composite_fwd(g(raw), g(z), g(rays), g(bc), with_fg=True, with_weights=True, **kw)
+            b = idn.ops.sample_pdf_fwd(g(z), a["weights"], g(u), Ni)
+            for with_w in (True, False):
+                m = idn.ops.march_fwd(g(raw), g(z), g(rays), g(bc), g(u), Ni, with_fg=True, with_weights=with_w, **kw)
+                assert ("weights" in m) == with_w
+                for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "last_weight", "rgb_fg") + (("weights",) if with_w else ()):
+                    assert torch.equal(m[k], a[k]), k
+                for k in ("z_samples", "inds", "cdf", "z_fine", "z_std"):
+                    assert torch.equal(m[k], b[k]), k
+
+
 def test_merge_handles_ties_unsorted_samples_and_nan(idn, dev):
     """z_fine == torch.sort(cat[z, z_samples]) whatever branch merges: sorted halves with exact ties
     (the binary-search merge), random u (unsorted samples: rank counting), and NaN depths (torch.sort
