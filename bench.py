@@ -501,6 +501,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:   # communicator set-up and the first all-gather of this size are not part of any step (--warmup 0 is legal)
+        parallel.gather_rows(torch.zeros((r1 - r0, W, 3), device=dev), H)
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
