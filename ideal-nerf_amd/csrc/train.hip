@@ -5,7 +5,7 @@
 //   composite_bwd     d(rgb_map, rgb_fg, last_weight, acc) -> d raw           (one wave per ray)
 //   delta chain       all delta_l = (delta_{l+1} . W_{l+1}) (.) [a_l > 0] in one fused kernel (mlp_f32_bwd.hip)
 //   gemm_tn           dW_l = delta_l^T . a_{l-1}, contraction over points, split over workgroups
-//   reduce_partials   sums the per-split dW blocks into the gradient tensors
+//   reduce_batch      sums the per-split dW blocks of all layers into the gradient tensors (one launch per pass)
 //   (db_l = sum_p delta_l comes out of gemm_tn's pass over delta_l)
 //   fold_bwd          conditioning columns of W0 / W5 / Wv0 and d aud, d latent
 //
@@ -307,23 +307,39 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 // out[n*ldo + k] = sum_s part[s][n][k],  n < rows, k < cols  (rows/cols may be smaller than N/K: padding dropped)
 // 64 outputs x 4 split lanes per block: lane q adds splits q, q+4, ... in fp64, the four lanes are
 // then added in a fixed order (deterministic), so 4x as many loads are in flight per output.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, int N, int K,
-                                                              float* __restrict__ out, int ldo, int rows, int cols) {
+// All partial-slab reductions of a pass in ONE launch (they were 27 launches of a few microseconds each per
+// pass, each waiting for the one before it).  Block b works on the item whose block range holds b.
+constexpr int kMaxReduceItems = 32;
+struct ReduceItem {
+    const float* part;   // [splits][N][K], already offset to the first row / column wanted
+    float* out;
+    int splits, N, K, ldo, rows, cols;
+    int block_end;       // exclusive end of this item's block range
+};
+struct ReduceBatch {
+    ReduceItem it[kMaxReduceItems];
+    int n;
+};
+__global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch b) {
     __shared__ double red[4][64];
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.it[i].block_end) ++i;   // block-uniform
+    const ReduceItem& t = b.it[i];
+    const int block0 = i ? b.it[i - 1].block_end : 0;
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o;
-    const bool live = idx < rows * cols;
-    const int n = live ? idx / cols : 0, k = live ? idx % cols : 0;
+    const int idx = ((int)blockIdx.x - block0) * 64 + o;
+    const bool live = idx < t.rows * t.cols;
+    const int n = live ? idx / t.cols : 0, k = live ? idx % t.cols : 0;
     double s = 0.0;
     if (live) {
-        const float* src = part + (long)n * K + k;
-        const long stride = (long)N * K;
+        const float* src = t.part + (long)n * t.K + k;
+        const long stride = (long)t.N * t.K;
 #pragma unroll 8
-        for (int sp = q; sp < splits; sp += 4) s += (double)src[sp * stride];
+        for (int sp = q; sp < t.splits; sp += 4) s += (double)src[sp * stride];
     }
     red[q][o] = s;
     __syncthreads();
-    if (q == 0 && live) out[(long)n * ldo + k] = (float)(((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
+    if (q == 0 && live) t.out[(long)n * t.ldo + k] = (float)(((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
 }
 
 // ---------------------------------------------------------------------------
@@ -492,12 +508,18 @@ __global__ void fold_bwd_kernel(FoldBwdArgs d) {
         const int k = idx - n_outer, n = k / d.p.dim_expr, e = k % d.p.dim_expr;
         d.gWv0[(long)n * ldv + IDN_W + IDN_VIEWS_CH + e] = d.dbv[n] * (d.expr[e] * 1.0f / 3.0f);
     } else {
-        const int c = idx - n_outer - (IDN_W / 2) * d.p.dim_expr;
+        // d cond[c]: one wavefront per conditioning column, the lanes split the 256 rows (a thread per column
+        // walked them as one chain of dependent strided loads: 65 us)
+        const int rel = idx - n_outer - (IDN_W / 2) * d.p.dim_expr;   // n_outer and 128 dim_expr are multiples of 64
+        const int c = rel >> 6, lane = rel & 63;
         if (c >= C) return;
         double s = 0.0;
-        for (int n = 0; n < IDN_W; ++n)
+        for (int n = lane; n < IDN_W; n += 64)
             s += (double)d.p.pts_w[0][(long)n * ld0 + IDN_PTS_CH + c] * (double)d.db0[n] +
                  (double)d.p.pts_w[5][(long)n * ld5 + IDN_PTS_CH + c] * (double)d.db5[n];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += shfl_xor_dd(s, m);
+        if (lane != 0) return;
         if (c < d.p.dim_aud) {
             if (d.d_aud) d.d_aud[c] += (float)s;
         } else if (c >= d.p.dim_aud + d.p.dim_expr) {
@@ -512,9 +534,12 @@ __global__ void fold_bwd_kernel(FoldBwdArgs d) {
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kMaxSplits = 256;
 constexpr int kColsumBlocks = 256;   // rows of the column-sum partial buffer (>= kMaxSplits)
+constexpr int kGemmsPerPass = 14;
+// partial-slab floats of one split over all GEMMs of a pass: 8 of 256x256, 3 of 256x64, 2 of 128x128, 1 of 64x128
+constexpr size_t kPartFloatsPerSplit = 8 * 65536 + 3 * 16384 + 2 * 16384 + 8192;
 
 struct BwdWs {
-    float *dA[8], *dV[2], *dV0, *dRGB, *part, *cpart, *dbtmp, *wbwd;
+    float *dA[8], *dV[2], *dV0, *dRGB, *part, *cpart, *wbwd;
     size_t bytes;
 };
 static BwdWs carve_bwd(char* base, int64_t p_pad) {
@@ -530,9 +555,8 @@ static BwdWs carve_bwd(char* base, int64_t p_pad) {
     w.dV[1] = take((size_t)p_pad * 128);
     w.dV0 = take((size_t)p_pad * 256);
     w.dRGB = take((size_t)p_pad * 64);
-    w.part = take((size_t)kMaxSplits * 256 * 256);
-    w.cpart = take((size_t)kColsumBlocks * 256);
-    w.dbtmp = take(1024);
+    w.part = take((size_t)kMaxSplits * kPartFloatsPerSplit);   // one slab per GEMM of the pass: they are all reduced at its end
+    w.cpart = take((size_t)kColsumBlocks * 256 * kGemmsPerPass);
     w.wbwd = take((size_t)kBwdStreamFrags * kFragFloats);               // transposed weight stream of the delta chain
     w.bytes = off;
     return w;
@@ -581,23 +605,50 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
     *splits_out = splits;
     return IDN_OK;
 }
-// out[(0..rows) x (0..cols)] (ld ldo) = sum over splits of part rows row0.. of the N x K product
-static int run_reduce(const float* part, int splits, int N, int K, int row0, float* out, int ldo, int rows, int cols,
-                      hipStream_t s) {
-    const int total = rows * cols;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part + (size_t)row0 * K,
-                       splits, N, K, out, ldo, rows, cols);
-    IDN_HIP_CHECK(hipGetLastError());
+// The reductions of a pass are queued and launched together (flush) once every GEMM has been issued.
+struct ReduceQueue {
+    ReduceBatch b;
+    int blocks = 0;
+    float* part_next;    // slab pools of the workspace
+    float* cpart_next;
+    ReduceQueue(float* part_pool, float* cpart_pool) : part_next(part_pool), cpart_next(cpart_pool) { b.n = 0; }
+    // out[(0..rows) x (0..cols)] (ld ldo) = sum over splits of the N x K partial blocks, from row row0 / column col0 on
+    int add(const float* part, int splits, int N, int K, int row0, int col0, float* out, int ldo, int rows, int cols) {
+        if (b.n >= kMaxReduceItems) return fail(IDN_EUNSUPPORTED, "reduce queue full");
+        blocks += (rows * cols + 63) / 64;
+        b.it[b.n++] = ReduceItem{part + (size_t)row0 * K + col0, out, splits, N, K, ldo, rows, cols, blocks};
+        return IDN_OK;
+    }
+    int flush(hipStream_t s) {
+        if (b.n == 0) return IDN_OK;
+        hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, b);
+        IDN_HIP_CHECK(hipGetLastError());
+        b.n = 0;
+        blocks = 0;
+        return IDN_OK;
+    }
+};
+// GEMM into a fresh slab of the pool; *part_out / *cpart_out are where its partial blocks went
+static int run_tn_q(ReduceQueue& q, const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, int* splits,
+                    const float** part_out, const float** cpart_out, bool colsum, hipStream_t s) {
+    float* part = q.part_next;
+    float* cpart = colsum ? q.cpart_next : nullptr;
+    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, splits, s, cpart)) return e;
+    q.part_next += (size_t)(*splits) * N * K;
+    if (colsum) q.cpart_next += (size_t)(*splits) * N;
+    *part_out = part;
+    if (cpart_out) *cpart_out = cpart;
     return IDN_OK;
 }
 // out = A^T B (rows x cols of it); db (optional, `db_cols` entries) = column sums of A, from the same pass over A
-static int run_tn(const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part, float* out,
-                  int ldo, int rows, int cols, hipStream_t s, float* cpart = nullptr, float* db = nullptr, int db_cols = 0) {
+static int run_tn(ReduceQueue& q, const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* out,
+                  int ldo, int rows, int cols, hipStream_t s, float* db = nullptr, int db_cols = 0) {
     int splits = 0;
-    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, &splits, s, db ? cpart : nullptr)) return e;
+    const float *part, *cpart;
+    if (int e = run_tn_q(q, A, lda, N, B, ldb, K, P, &splits, &part, &cpart, db != nullptr, s)) return e;
     if (db)
-        if (int e = run_reduce(cpart, splits, 1, N, 0, db, N, 1, db_cols, s)) return e;
-    return run_reduce(part, splits, N, K, 0, out, ldo, rows, cols, s);
+        if (int e = q.add(cpart, splits, 1, N, 0, 0, db, N, 1, db_cols)) return e;
+    return q.add(part, splits, N, K, 0, 0, out, ldo, rows, cols);
 }
 
 int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, const float* aud, const float* expr,
@@ -636,36 +687,38 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
     TRY(launch_pack_f32_bwd(p, w.wbwd, s));
     TRY(launch_delta_chain(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
     // weight and bias gradients: dW_l = delta_l^T a_{l-1} (contraction over the points), db_l = column sums
-    TRY(run_tn(w.dRGB, 64, 64, v_l(3), 128, 128, Pp, w.part, gr.rgb_w, 128, 3, 128, s, w.cpart, gr.rgb_b, 3));
-    TRY(run_tn(w.dV[0], 128, 128, v_l(2), 128, 128, Pp, w.part, gr.views_w[2], 128, 128, 128, s, w.cpart, gr.views_b[2], 128));
-    TRY(run_tn(w.dV[1], 128, 128, v_l(1), 128, 128, Pp, w.part, gr.views_w[1], 128, 128, 128, s, w.cpart, gr.views_b[1], 128));
+    ReduceQueue q(w.part, w.cpart);
+    TRY(run_tn(q, w.dRGB, 64, 64, v_l(3), 128, 128, Pp, gr.rgb_w, 128, 3, 128, s, gr.rgb_b, 3));
+    TRY(run_tn(q, w.dV[0], 128, 128, v_l(2), 128, 128, Pp, gr.views_w[2], 128, 128, 128, s, gr.views_b[2], 128));
+    TRY(run_tn(q, w.dV[1], 128, 128, v_l(1), 128, 128, Pp, gr.views_w[1], 128, 128, 128, s, gr.views_b[1], 128));
     // views_linears.0 (+ alpha_linear as channel 128); inputs [a8 | dirPE | expr(folded)]
     {
         int splits = 0;
-        TRY(run_tn_partials(w.dV0, 256, 256, a_l(8), 256, 256, Pp, w.part, &splits, s, w.cpart));
-        TRY(run_reduce(w.cpart, splits, 1, 256, 0, w.dbtmp, 256, 1, 256, s));
-        TRY(run_reduce(w.part, splits, 256, 256, 0, gr.views_w[0], ldv, 128, 256, s));
-        TRY(run_reduce(w.part, splits, 256, 256, kSigmaChannel, gr.alpha_w, 256, 1, 256, s));
-        TRY(run_tn_partials(w.dV0, 256, 256, act(kActDir), 64, 64, Pp, w.part, &splits, s));
-        TRY(run_reduce(w.part, splits, 256, 64, 0, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH, s));
-        IDN_HIP_CHECK(hipMemcpyAsync(gr.views_b[0], w.dbtmp, 128 * 4, hipMemcpyDeviceToDevice, s));
-        IDN_HIP_CHECK(hipMemcpyAsync(gr.alpha_b, w.dbtmp + kSigmaChannel, 4, hipMemcpyDeviceToDevice, s));
+        const float *part, *cpart;
+        TRY(run_tn_q(q, w.dV0, 256, 256, a_l(8), 256, 256, Pp, &splits, &part, &cpart, true, s));
+        TRY(q.add(cpart, splits, 1, 256, 0, 0, gr.views_b[0], 256, 1, 128));
+        TRY(q.add(cpart, splits, 1, 256, 0, kSigmaChannel, gr.alpha_b, 256, 1, 1));
+        TRY(q.add(part, splits, 256, 256, 0, 0, gr.views_w[0], ldv, 128, 256));
+        TRY(q.add(part, splits, 256, 256, kSigmaChannel, 0, gr.alpha_w, 256, 1, 256));
+        TRY(run_tn_q(q, w.dV0, 256, 256, act(kActDir), 64, 64, Pp, &splits, &part, nullptr, false, s));
+        TRY(q.add(part, splits, 256, 64, 0, 0, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH));
     }
     for (int l = 7; l >= 1; --l) {
         const float* cur = w.dA[l];
         if (l == 5) {
-            TRY(run_tn(cur, 256, 256, a_l(5), 256, 256, Pp, w.part, gr.pts_w[5] + IDN_PTS_CH + C, ld5, 256, 256, s, w.cpart, gr.pts_b[5], 256));
-            TRY(run_tn(cur, 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[5], ld5, 256, IDN_PTS_CH, s));
+            TRY(run_tn(q, cur, 256, 256, a_l(5), 256, 256, Pp, gr.pts_w[5] + IDN_PTS_CH + C, ld5, 256, 256, s, gr.pts_b[5], 256));
+            TRY(run_tn(q, cur, 256, 256, act(kActX0), 64, 64, Pp, gr.pts_w[5], ld5, 256, IDN_PTS_CH, s));
         } else {
-            TRY(run_tn(cur, 256, 256, a_l(l), 256, 256, Pp, w.part, gr.pts_w[l], 256, 256, 256, s, w.cpart, gr.pts_b[l], 256));
+            TRY(run_tn(q, cur, 256, 256, a_l(l), 256, 256, Pp, gr.pts_w[l], 256, 256, 256, s, gr.pts_b[l], 256));
         }
     }
-    TRY(run_tn(w.dA[0], 256, 256, act(kActX0), 64, 64, Pp, w.part, gr.pts_w[0], ld0, 256, IDN_PTS_CH, s, w.cpart, gr.pts_b[0], 256));
+    TRY(run_tn(q, w.dA[0], 256, 256, act(kActX0), 64, 64, Pp, gr.pts_w[0], ld0, 256, IDN_PTS_CH, s, gr.pts_b[0], 256));
+    TRY(q.flush(s));
 #undef TRY
     {
         FoldBwdArgs f{p, aud, expr, latent, gr.pts_b[0], gr.pts_b[5], gr.views_b[0], gr.pts_w[0], gr.pts_w[5],
                       gr.views_w[0], d_aud, d_latent};
-        const int total = IDN_W * C + (IDN_W / 2) * p.dim_expr + C;
+        const int total = IDN_W * C + (IDN_W / 2) * p.dim_expr + C * 64;   // one wavefront per conditioning column at the end
         if (total > 0) {
             hipLaunchKernelGGL(fold_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, f);
             IDN_HIP_CHECK(hipGetLastError());

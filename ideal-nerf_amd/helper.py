@@ -39,8 +39,17 @@ def img2mse(x, y):
     return torch.nn.functional.mse_loss(x, y)
 
 
+_log10_cache = {}
+
+
 def mse2psnr(x):
-    return -10.0 * torch.log(x) / torch.log(torch.tensor([10.0], device=x.device))
+    """helper.py:151: -10 log(x) / log(Tensor([10.])).  The constant is built once per device: creating it from a
+    Python list on every call is a blocking host-to-device copy, i.e. a full stream synchronisation in the middle
+    of every training step (the host could not queue the backward while the forward ran)."""
+    c = _log10_cache.get(x.device)
+    if c is None:
+        c = _log10_cache[x.device] = torch.log(torch.tensor([10.0])).to(x.device)
+    return -10.0 * torch.log(x) / c
 
 
 def to8b(x):

@@ -7,6 +7,31 @@ the HIP kernels, not part of the measured hot loop.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _conv1d_k3(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
+    """``conv(x)`` for the reference's kernel-3, padding-1 convolutions on [n, C_in, L <= 16] as a gather of
+    the L_out windows and ONE matrix product with the [C_out, 3 C_in] weight.  Same parameters, same result to
+    fp32 rounding -- but on ROCm ``nn.Conv1d`` at these sizes goes to MIOpen's ``naive_conv_*`` kernels and
+    their layout transposes: ~50 launches and 0.6 ms per training step, against ~0.1 ms this way."""
+    stride = conv.stride[0]
+    cols = F.pad(x, (1, 1)).unfold(2, 3, stride)                # [n, C_in, L_out, 3] (a view)
+    n, c_in, l_out, _ = cols.shape
+    cols = cols.permute(0, 2, 1, 3).reshape(n * l_out, c_in * 3)
+    y = F.linear(cols, conv.weight.reshape(conv.out_channels, c_in * 3), conv.bias)
+    return y.reshape(n, l_out, conv.out_channels).permute(0, 2, 1)
+
+
+def _run_convnet(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    for layer in seq:
+        if isinstance(layer, nn.Conv1d) and layer.kernel_size == (3,) and layer.padding == (1,) and x.is_cuda:
+            x = _conv1d_k3(x, layer)
+        elif isinstance(layer, nn.LeakyReLU):
+            x = F.leaky_relu(x, layer.negative_slope)
+        else:
+            x = layer(x)
+    return x
 
 
 class AudioAttNet(nn.Module):
@@ -22,8 +47,8 @@ class AudioAttNet(nn.Module):
 
     def forward(self, x):  # x: [seq_len, >=dim_aud]
         y = x[..., :self.dim_aud].permute(1, 0).unsqueeze(0)
-        y = self.attentionConvNet(y)
-        y = self.attentionNet(y.view(1, self.seq_len)).view(self.seq_len, 1)
+        y = _run_convnet(self.attentionConvNet, y)
+        y = self.attentionNet(y.reshape(1, self.seq_len)).view(self.seq_len, 1)
         return torch.sum(y * x, dim=0)
 
 
@@ -41,7 +66,7 @@ class AudioNet(nn.Module):
     def forward(self, x):  # x: [n, 16, 29]
         half_w = int(self.win_size / 2)
         x = x[:, 8 - half_w:8 + half_w, :].permute(0, 2, 1)
-        x = self.encoder_conv(x).squeeze(-1)
+        x = _run_convnet(self.encoder_conv, x).squeeze(-1)
         return self.encoder_fc1(x).squeeze()
 
 
@@ -78,6 +103,6 @@ def clip_audio_features(aud_net: AudioNet, aud_att_net: AudioAttNet, auds: torch
     idx = torch.where((idx >= 0) & (idx < F), idx, torch.full_like(idx, F))
     win = table[idx]                                                  # [F, smo, dim_aud]
     y = win[..., :aud_att_net.dim_aud].permute(0, 2, 1)               # [F, dim_att, smo]
-    y = aud_att_net.attentionConvNet(y)                               # [F, 1, smo]
+    y = _run_convnet(aud_att_net.attentionConvNet, y)                 # [F, 1, smo]
     y = aud_att_net.attentionNet(y.reshape(F, aud_att_net.seq_len))   # softmax over the window
     return torch.sum(y.unsqueeze(-1) * win, dim=1)

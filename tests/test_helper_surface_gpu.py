@@ -322,3 +322,43 @@ def test_render_switches_golden(idn, dev, golden, frame_net):
         assert rel_err(out["rgb_map"], g["rr_lindisp_rgb_map"]) < RGB_TOL and out["rgb_map"].requires_grad
     finally:
         net.eval()
+
+
+# --------------------------------------------------------------------------- audio nets on the GPU
+def test_audio_nets_on_gpu_match_reference_and_conv_autograd(idn, dev, golden):
+    """On the GPU the kernel-3 convolutions of AudioNet / AudioAttNet run as a window gather + one matrix
+    product (MIOpen's naive conv kernels stay off the training step): forward against the reference's outputs,
+    gradients against nn.Conv1d's own autograd on the CPU, and the batched clip pass against the per-frame loop."""
+    from idealnerf_amd.models.audio_net import AudioAttNet, AudioNet, DeepSpeechAudNet, clip_audio_features
+    g = golden("audio_nets")
+    nets = {"aud": AudioNet(64, 16), "att": AudioAttNet(), "ds": DeepSpeechAudNet()}
+    for tag, m in nets.items():
+        m.load_state_dict({k[len(tag) + 4:]: T(v) for k, v in g.items() if k.startswith(tag + "_sd_")}, strict=True)
+    cpu_nets = {k: type(m)(*((64, 16) if k == "aud" else ())) for k, m in nets.items()}
+    for k in nets:
+        cpu_nets[k].load_state_dict(nets[k].state_dict())
+        nets[k].to(dev)
+    auds = T(g["aud_in"]).to(dev)
+    with torch.no_grad():
+        out8 = nets["aud"](auds)
+        np.testing.assert_allclose(out8.cpu().numpy(), g["aud_out8"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(nets["aud"](auds[3:4]).cpu().numpy(), g["aud_out1"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(nets["att"](out8).cpu().numpy(), g["att_out"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(nets["ds"](auds[3:4]).cpu().numpy(), g["ds_out"], rtol=2e-5, atol=2e-6)
+    # gradients of a scalar through AudioNet -> AudioAttNet: GPU (matmul form) vs CPU (nn.Conv1d)
+    w = T(np.random.RandomState(3).standard_normal(64).astype(np.float32))
+    loss_gpu = (nets["att"](nets["aud"](auds)) * w.to(dev)).sum()
+    loss_cpu = (cpu_nets["att"](cpu_nets["aud"](auds.cpu())) * w).sum()
+    loss_gpu.backward()
+    loss_cpu.backward()
+    assert abs(float(loss_gpu) - float(loss_cpu)) < 1e-5 * max(1.0, abs(float(loss_cpu)))
+    for k in ("aud", "att"):
+        for (name, p), (_, q) in zip(nets[k].named_parameters(), cpu_nets[k].named_parameters()):
+            assert rel_err(p.grad, q.grad) < 2e-4, (k, name)
+    c = golden("audio_clip")
+    aud_net, att_net = AudioNet(64, 16), AudioAttNet()
+    aud_net.load_state_dict({k[len("audnet."):]: T(v) for k, v in c.items() if k.startswith("audnet.")})
+    att_net.load_state_dict({k[len("attnet."):]: T(v) for k, v in c.items() if k.startswith("attnet.")})
+    with torch.no_grad():
+        feats = clip_audio_features(aud_net.to(dev), att_net.to(dev), T(c["auds"]).to(dev))
+    np.testing.assert_allclose(feats.cpu().numpy(), c["out"], rtol=2e-5, atol=2e-6)
