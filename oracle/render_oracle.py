@@ -25,7 +25,7 @@ __all__ = [
     "facenerf_dims", "facenerf_param_shapes", "xavier_facenerf_params",
     "facenerf_forward", "composite", "importance_cdf", "invert_cdf",
     "sample_importance", "coarse_depths", "render_rays", "render_frame",
-    "torso_signal", "pose_to_euler_trans", "head_torso_composite", "train_loss",
+    "torso_signal", "pose_to_euler_trans", "head_torso_composite", "train_loss", "to_f64", "fp32_noise_floor",
     "mse_to_psnr", "synthetic_frame",
 ]
 
@@ -470,3 +470,27 @@ def synthetic_frame(H: int = 512, W: int = 512, seed: int = 0, dims=None):
     return dict(H=H, W=W, focal=1200.0 * W / 450.0, c2w=torch.from_numpy(c2w),
                 near=0.5772005200386048, far=1.1772005200386046, bc=torch.from_numpy(bc),
                 aud=t(aud), expr=t(expr), latent=t(latent))
+
+
+# --------------------------------------------------------------------------
+# How far is the fp32 formula itself from exact arithmetic on a given scene?
+# --------------------------------------------------------------------------
+def to_f64(x):
+    """Tensors (also inside dicts / lists / tuples) as float64; everything else unchanged."""
+    if torch.is_tensor(x):
+        return x.double() if x.is_floating_point() else x
+    if isinstance(x, dict):
+        return {k: to_f64(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(to_f64(v) for v in x)
+    return x
+
+
+def fp32_noise_floor(ref32: torch.Tensor, ref64: torch.Tensor) -> float:
+    """max |ref32 - ref64| / max |ref64|: the distance of the reference's OWN fp32 evaluation from the same
+    formulas in fp64.  The importance sampling divides by bin masses floored at 1e-5, so where the density is
+    sharp a last-ulp difference in a coarse weight relocates fine samples and moves a pixel by ~1e-4: on such
+    scenes two correct fp32 implementations (CPU BLAS vs fp32 MFMA, or the same CPU code on two hosts) differ
+    by about this much, and neither can be asked to match the other more closely."""
+    a, b = ref32.detach().double(), ref64.detach().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

