@@ -49,10 +49,24 @@ def abs_err(a, b):
 
 
 def rgb_budget(ref32, ref64, tol=None):
-    """Bound for a comparison with an oracle evaluated AT RUN TIME (the goldens are fixed numbers; a live
-    oracle run depends on the host's BLAS): the 1e-4 budget, or twice the oracle's own fp32-vs-fp64 distance on
-    this scene where that is larger (oracle.fp32_noise_floor) -- measured 3e-5 .. 4e-4 on the sharp scenes here."""
-    return max(RGB_TOL if tol is None else tol, 2.0 * oracle.fp32_noise_floor(ref32, ref64))
+    """Twice the oracle's own fp32-vs-fp64 distance on this scene (oracle.fp32_noise_floor), at least the 1e-4
+    budget -- measured 3e-7 .. 4e-4 on the scenes here."""
+    return max(RGB_TOL if tol is None else tol, 2.0 * rel_err(ref32, ref64))
+
+
+def rgb_ok(out, ref32, ref64, what=""):
+    """Acceptance for a comparison with an oracle evaluated AT RUN TIME (the goldens are fixed numbers; a live
+    oracle run depends on the host's BLAS, and on sharp scenes the fp32 formula itself sits ~1e-4 from exact
+    arithmetic): within the 1e-4 budget of the fp32 oracle -- or, where the oracle's own distance from the same
+    formulas in fp64 is of that size, no further from the fp64 result than twice that distance (i.e. as good
+    an fp32 evaluation as the reference's)."""
+    e32 = rel_err(out, ref32)
+    if e32 < RGB_TOL:
+        return True
+    e64, budget = rel_err(out, ref64), rgb_budget(ref32, ref64)
+    print(f"\n  {what}: {e32:.2e} from the fp32 oracle, {e64:.2e} from fp64 (oracle's own distance "
+          f"{rel_err(ref32, ref64):.2e}, bound {budget:.2e})")
+    return e64 < budget
 
 
 # Quantities bounded by 1 (weights, transmittance tails, cdf) are compared absolutely.
@@ -520,7 +534,7 @@ def test_full_size_band_properties(idn, dev):
     with torch.no_grad():
         ref = oracle.render_rays(rays[idx].cpu(), bc[idx].cpu(), pc, pf, *cond, dims=dims)
         ref64 = oracle.render_rays(*oracle.to_f64((rays[idx].cpu(), bc[idx].cpu(), pc, pf, *cond)), dims=dims)
-    assert rel_err(full["rgb_map"][idx], ref["rgb_map"]) < rgb_budget(ref["rgb_map"], ref64["rgb_map"])
+    assert rgb_ok(full["rgb_map"][idx], ref["rgb_map"], ref64["rgb_map"], "full-size band")
 
 
 # --------------------------------------------------------------------------- a12: training step
@@ -702,7 +716,7 @@ def test_head_torso_composite_matches_oracle(idn, dev):
     (ref, ref0), _ = _torso_oracle(net, P, dims, d)
     (ref64, _), _ = _torso_oracle(net, P, dims, d, f64=True)
     assert rgb_com.shape == (48, 3)
-    assert rel_err(rgb_com, ref) < rgb_budget(ref, ref64) and rel_err(rgb_com0, ref0) < RGB_TOL
+    assert rgb_ok(rgb_com, ref, ref64, "head+torso composite") and rel_err(rgb_com0, ref0) < RGB_TOL
 
 
 def test_torso_signal_golden(idn, dev, golden):
@@ -1189,7 +1203,7 @@ def test_render_unusual_sample_counts_vs_oracle(idn, dev, n_rays, S, Ni):
     t, u = torch.linspace(0.0, 1.0, S).to(dev), torch.linspace(0.0, 1.0, Ni).to(dev)
     out = idn.ops.render_rays_fwd(r, bc.to(dev), pk_c, fold_c(*cond), pk_f, fold_f(*cond), t, u, Ni)
     for k in ("rgb_map", "rgb0", "disp_map", "acc_map"):
-        assert rel_err(out[k], ref[k]) < rgb_budget(ref[k], ref64[k]), k
+        assert rgb_ok(out[k], ref[k], ref64[k], k), k
     assert abs_err(out["last_weight"], ref["last_weight"]) < W_TOL
 
 
@@ -1251,7 +1265,7 @@ def test_head_torso_composite_bf16_modes_psnr(idn, dev):
     o3, o1 = psnr(outs["bf16x3"][0], ref), psnr(outs["bf16"][0], ref)
     print(f"head+torso composite vs CPU oracle: fp32 max rel {rel_err(outs['f32'][0], ref):.1e} (budget {budget:.1e}: the oracle's "
           f"own fp32-vs-fp64 distance x 2), bf16x3 PSNR {o3:.1f} dB, plain bf16 PSNR {o1:.1f} dB")
-    assert rel_err(outs["f32"][0], ref) < budget and rel_err(outs["f32"][1], ref0) < RGB_TOL   # sharp scene: see the mixed test
+    assert rgb_ok(outs["f32"][0], ref, ref64.numpy(), "head+torso fp32") and rel_err(outs["f32"][1], ref0) < RGB_TOL   # sharp scene: see the mixed test
     assert o3 > 60.0 and o1 > 40.0
     assert rel_err(outs["bf16x3"][1], ref0) < RGB_TOL
 
@@ -1291,7 +1305,7 @@ def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golde
     for mode in ("f32", "mixed"):
         per_ray = np.abs(outs[mode][0] - ref_np).max(1) / np.abs(ref_np).max()
         print(f"  {mode}: rays beyond 1e-4 of the frame maximum: {(per_ray > RGB_TOL).mean():.2%}")
-        assert per_ray.max() < budget and (per_ray > RGB_TOL).mean() < 0.01
+        assert rgb_ok(outs[mode][0], ref, ref64, f"head+torso {mode}") and (per_ray > RGB_TOL).mean() < 0.01
         assert rel_err(outs[mode][1], ref0) < RGB_TOL
 
     g = golden("frame32")
@@ -1341,7 +1355,7 @@ def test_random_scenes_fp32_and_mixed_vs_oracle(idn, dev, seed):
                                       precision=prec_c, precision_fine=prec_f)
         for k in ("rgb_map", "rgb0", "disp_map", "acc_map", "last_weight", "z_std"):
             assert bool(torch.isfinite(out[k]).all()), (mode, k)
-        assert rel_err(out["rgb_map"], ref["rgb_map"]) < rgb_budget(ref["rgb_map"], ref64["rgb_map"]), mode
+        assert rgb_ok(out["rgb_map"], ref["rgb_map"], ref64["rgb_map"], f"scene {seed} {mode}"), mode
         assert rel_err(out["rgb0"], ref["rgb0"]) < RGB_TOL, mode   # the coarse composite has no sampling before it
 
 
