@@ -219,7 +219,7 @@ int idealnerf_invert_cdf(const float* cdf, const float* bins, const float* u, in
 
 size_t idealnerf_train_acts_floats(int64_t n_points) {
     if (n_points <= 0) return 0;
-    return (size_t)((n_points + 127) / 128 * 128) * kActCols;
+    return (size_t)((n_points + 127) / 128 * 128) * kActColsAll;
 }
 
 int idealnerf_query_rays_train_fwd(const float* packed, const float* folded, int precision, const float* rays,

@@ -109,6 +109,17 @@ constexpr int act_off(int i) {
 }
 constexpr int kActCols = act_off(kActCount);  // 2560
 static_assert(kActCols == 2560, "activation slab layout changed");
+// Behind the matrices: the ReLU masks of the 11 hidden layers as BITS, in the accumulator layout both MLP
+// kernels share, so the backward delta chain loads one uint4 per lane and layer instead of gathering 16-byte
+// pieces of the saved activations.  Layer id 0..7 = a1..a8, 8..10 = v1..v3; entry
+// [id][wave tile = point / 32][lane] is a uint4 whose dword k holds tiles 2k, 2k+1: bit 31 - (16 (T & 1) + r)
+// = sign bit of the PRE-activation of register r of tile T (1 = the unit is off).
+constexpr int kMaskLayers = 11;
+constexpr int kMaskFloatsPerPoint = kMaskLayers * 8;   // 2 lanes x 4 dwords per point and layer
+constexpr int kActColsAll = kActCols + kMaskFloatsPerPoint;
+__host__ __device__ inline size_t mask_index(int id, int64_t p_pad, int64_t wave_tile, int lane) {
+    return ((size_t)id * (size_t)(p_pad / 32) + (size_t)wave_tile) * 64 + (size_t)lane;   // in uint4 units
+}
 
 // ---------------------------------------------------------------------------
 // error plumbing (capi.hip)

@@ -115,9 +115,19 @@ struct LayerSide {
 // (as plain loads each one was followed by `lgkmcnt(0)`: sixteen exposed round trips per tile).
 // Every row of the p_pad-row slab is written -- padding rows repeat the last point -- because the
 // weight-gradient GEMMs contract over all p_pad rows (their deltas are zero, but 0 x garbage is not).
+// Sign bits of a tile's 16 pre-activations pushed into mask dword T / 2 (idn_internal.h "ReLU masks"):
+// one v_alignbit per value, (mk << 1) | (x >> 31).
+template <int T>
+__device__ __forceinline__ void collect_signs(const f32x16& tile, uint32_t* mk) {
+    static_for<16>([&](auto R) {
+        mk[T >> 1] = __builtin_amdgcn_alignbit(mk[T >> 1], __float_as_uint(tile[decltype(R)::value]), 31);
+    });
+}
+
 template <int NT, int STEPS, int LD>
 struct SaveSide {
     static constexpr bool kShadowStore = STEPS >= 8;
+    uint32_t* mk;     // [4] ReLU mask bits of this layer, collected tile by tile
     f32x16* out;
     __amdgpu_buffer_rsrc_t rsrc;   // this wave's 32 rows of the activation matrix (LD floats per row)
     uint32_t voff;                 // byte offset of [row h][column m]
@@ -159,6 +169,8 @@ struct SaveSide {
         });
     }
     __device__ __forceinline__ void finish() const {   // after the layer: what the shadow schedule did not cover
+        if constexpr (!kShadowStore) static_for<NT - 1>([&](auto T) { collect_signs<decltype(T)::value>(out[decltype(T)::value], mk); });
+        collect_signs<NT - 1>(out[NT - 1], mk);   // tiles in order: the bits of a dword are pushed oldest first
         relu_regs<0, 16>(out[NT - 1]);
         if constexpr (kShadowStore) flush_tile(ic<NT - 1>{});
         else {
@@ -169,7 +181,10 @@ struct SaveSide {
     template <int T, int S, int H>
     __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {
         if constexpr (kShadowStore && T > 0 && H == 0) {
-            if constexpr (S == 0) relu_regs<0, 16>(out[T - 1]);
+            if constexpr (S == 0) {
+                collect_signs<T - 1>(out[T - 1], mk);
+                relu_regs<0, 16>(out[T - 1]);
+            }
             if constexpr (S == 1) scatter(ic<T - 1>{});
             if constexpr (S >= 3 && S <= 6) rows_store(ic<T - 1>{}, ic<S - 3>{});
             if constexpr (S >= 2 && S <= 5) rows_read(ic<S - 2>{});
@@ -272,6 +287,12 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         // (accumulators); a finished layer's output is ReLU'd in place and read by the next.
         f32x16 A[8], B[8], V[5];
         float rb[4];
+        uint32_t mk[4] = {0u, 0u, 0u, 0u};   // SAVE: the current layer's ReLU mask bits
+        auto store_mask = [&](int id) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(id, a.p_pad, tile * 4 + wave, lane);
+            *mp = u32x4{mk[0], mk[1], mk[2], mk[3]};
+        };
         auto pe_get = [&](auto G, auto J) { return pe[decltype(G)::value][decltype(J)::value]; };
         auto tiles_get = [](f32x16* arr) {
             return [arr](auto G, auto J) {
@@ -301,10 +322,11 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
             DIAG_END(dg, kDgBoundary);
             if constexpr (SAVE) {
                 if (save_idx >= 0) {  // hidden layer: ReLU + record, in the MFMA shadow
-                    const SaveSide<NT, KG / 2, 32 * NT> side{&out[0], rows_rsrc(a.acts + (long)act_off(save_idx) * a.p_pad + p0 * (32 * NT), 32 * NT),
+                    const SaveSide<NT, KG / 2, 32 * NT> side{mk, &out[0], rows_rsrc(a.acts + (long)act_off(save_idx) * a.p_pad + p0 * (32 * NT), 32 * NT),
                                                              (uint32_t)((h * (32 * NT) + m) * 4), stage, rb, raddr, m, h};
                     run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, side, hook);
                     side.finish();
+                    store_mask(save_idx - kActA1);   // a1..a8 -> 0..7, v2 / v3 -> 9 / 10
                 } else {
                     run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, NoSide{}, hook);
                 }
@@ -374,8 +396,10 @@ __global__ __launch_bounds__(256, 1) void mlp_f32_kernel(MlpArgs a) {
         if constexpr (SAVE) {
             DIAG_BEGIN(dg);
             f32x16(&V4)[4] = reinterpret_cast<f32x16(&)[4]>(V);
+            static_for<4>([&](auto T) { collect_signs<decltype(T)::value>(V4[decltype(T)::value], mk); });
+            store_mask(kActV1 - kActA1);   // v1 -> 8
             relu_tiles<4>(V4);
-            const SaveSide<4, 1, 128> side{&V4[0], rows_rsrc(a.acts + (long)act_off(kActV1) * a.p_pad + p0 * 128, 128),
+            const SaveSide<4, 1, 128> side{mk, &V4[0], rows_rsrc(a.acts + (long)act_off(kActV1) * a.p_pad + p0 * 128, 128),
                                            (uint32_t)((h * 128 + m) * 4), stage, rb, raddr, m, h};
             static_for<4>([&](auto T) { side.flush_tile(T); });
             DIAG_END(dg, kDgBoundary);

@@ -129,8 +129,10 @@ __device__ __forceinline__ void run_stage(f32x16 (&out)[NT], BGet&& bget, WStrea
     fr.pref1 = a1;
 }
 
-// In the shadow of tile t's MFMAs (pair-steps 0 ..): the mask of tile t is loaded (step 0), the
-// finished tile t-1 is masked (step 1), scattered into the wave's LDS patch (step 2) and written
+// In the shadow of tile t's MFMAs (pair-steps 0 ..): the finished tile t-1 is masked (step 1) with the
+// layer's ReLU bits (one uint4 per lane and layer, written by the forward in this very accumulator layout and
+// loaded a whole stage ahead; gathering the saved activations instead cost four 16-byte loads per tile and most
+// of the kernel's parked cycles), scattered into the wave's LDS patch (step 2) and written
 // out as row segments: the four row values of quad q are READ from the patch at step 3 + q and
 // STORED at step 4 + q.  The patch reads are inline asm like the fragment reads: LDS returns in
 // order, so the pair-step's counted `lgkmcnt(2)` (FragReader::retire) has covered them by the time
@@ -141,8 +143,7 @@ template <int NT, int STEPS, int LD>
 struct MaskSide {
     static constexpr bool kShadowStore = STEPS >= 8;
     f32x16* out;
-    f32x4 (*mbuf)[4];          // [2][4]: double-buffered masks, 4 quads of 4 channels
-    const float* mrow;         // activation row of this lane's point + 4h
+    const uint32_t* mk;        // [4] mask bits of this layer: dword k = tiles 2k, 2k+1, value i of the pair at bit 31 - i
     __amdgpu_buffer_rsrc_t rsrc;  // this wave's 32 rows of the delta matrix (LD floats per row)
     uint32_t voff;             // byte offset of [row h][column m]
     float* stage;              // this wave's 32 x 33 transpose patch
@@ -150,17 +151,12 @@ struct MaskSide {
     uint32_t raddr;            // LDS byte address of patch[h][m]
     int m, h;
     template <int T>
-    __device__ __forceinline__ void load(ic<T>) const {
-        static_for<4>([&](auto Q) {
-            constexpr int q = decltype(Q)::value;
-            mbuf[T & 1][q] = *reinterpret_cast<const f32x4*>(mrow + 32 * T + 8 * q);
-        });
-    }
-    template <int T>
     __device__ __forceinline__ void apply(ic<T>) const {
+        const uint32_t w = mk[T >> 1];
         static_for<16>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            out[T][r] = mbuf[T & 1][r >> 2][r & 3] > 0.0f ? out[T][r] : 0.0f;
+            constexpr int r = decltype(R)::value, i = 16 * (T & 1) + r;
+            const int off = (int)(w << i) >> 31;   // all ones where the unit was off (sign bit of its pre-activation)
+            out[T][r] = __uint_as_float(__float_as_uint(out[T][r]) & ~(uint32_t)off);
         });
     }
     template <int T>
@@ -205,7 +201,6 @@ struct MaskSide {
     __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {
         constexpr int kApplyStep = STEPS > 1 ? 1 : 0;   // a one-step stage (rgb_linear^T) applies before it reloads
         if constexpr (S == kApplyStep && T > 0) apply(ic<T - 1>{});
-        if constexpr (S == 0) load(ic<T>{});
         if constexpr (kShadowStore && T > 0) {
             if constexpr (S == 2) scatter(ic<T - 1>{});
             if constexpr (S >= 4 && S <= 7) rows_store(ic<T - 1>{}, ic<S - 4>{});
@@ -244,15 +239,17 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long p0 = tile * 128 + wave * 32;
         const long P = p0 + m;
-        const float* arow = a.acts + 4 * h;  // + act_off(i) * p_pad + P * width(i): per stage below
-        auto act_row = [&](int idx, int width) { return arow + (long)act_off(idx) * a.p_pad + P * width; };
         // d raw of this lane's point: rgb in k-channels 0..2 (lane half 0), sigma in k-channel 128
         const f32x4 drgb = *reinterpret_cast<const f32x4*>(a.d_rgb + P * 64);
         const float dsig = a.dv0[P * 256 + kSigmaChannel];
 
         f32x16 A[8], B[8];
-        f32x4 mbuf[2][4];
         float rb[4];
+        // ReLU masks: mask_use = this stage's bits, mask_nxt = the next stage's, in flight since the previous stage began
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* mbase = reinterpret_cast<const u32x4*>(a.acts + (size_t)kActCols * a.p_pad);
+        auto mask_load = [&](int id) { return mbase[mask_index(id, a.p_pad, tile * 4 + wave, lane)]; };
+        u32x4 mask_nxt = mask_load(10);
         auto tiles_get = [](f32x16* arr) {
             return [arr](auto G, auto J) {
                 constexpr int g = decltype(G)::value, j = decltype(J)::value;
@@ -260,12 +257,16 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
             };
         };
         // one stage: zero accumulators, MFMAs with the mask in their shadow, last tile's mask, store
-        auto stage_run = [&](auto Sc, auto F0c, auto LASTc, auto LDc, auto& out, auto&& bget, const float* mrow, float* dst) {
+        // `next_id`: the mask layer of the stage after this one (-1: none), loaded now and used then
+        auto stage_run = [&](auto Sc, auto F0c, auto LASTc, auto LDc, auto& out, auto&& bget, int next_id, float* dst) {
             constexpr int S = decltype(Sc)::value, F0 = decltype(F0c)::value;
             constexpr int NT = kBwdNT[S], KG = kBwdKG[S];
             zero_tiles<NT>(out);
             constexpr int LD = decltype(LDc)::value;
-            const MaskSide<NT, KG / 2, LD> side{&out[0], mbuf, mrow, rows_rsrc(dst + p0 * LD, LD), (uint32_t)((h * LD + m) * 4), stage, rb, raddr, m, h};
+            const u32x4 mv = mask_nxt;
+            const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
+            if (next_id >= 0) mask_nxt = mask_load(next_id);
+            const MaskSide<NT, KG / 2, LD> side{&out[0], mk, rows_rsrc(dst + p0 * LD, LD), (uint32_t)((h * LD + m) * 4), stage, rb, raddr, m, h};
             run_stage<F0, NT, KG, decltype(LASTc)::value != 0>(out, bget, ws, fr, side);
             side.finish();
         };
@@ -279,10 +280,10 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
                       if constexpr (g == 0 && j < 3) return h ? 0.0f : drgb[j];
                       else return 0.0f;
                   },
-                  act_row(kActV1 + 2, 128), a.dv2);
+                  9, a.dv2);
         // 1: views_linears.2^T -> delta of views_linears.1 (mask v2);  2: views_linears.1^T -> views_linears.0 (mask v1)
-        stage_run(ic<1>{}, ic<bwd_f0(1)>{}, ic<0>{}, ic<128>{}, B4, tiles_get(A), act_row(kActV1 + 1, 128), a.dv1);
-        stage_run(ic<2>{}, ic<bwd_f0(2)>{}, ic<0>{}, ic<256>{}, A4, tiles_get(B), act_row(kActV1 + 0, 128), a.dv0);
+        stage_run(ic<1>{}, ic<bwd_f0(1)>{}, ic<0>{}, ic<128>{}, B4, tiles_get(A), 8, a.dv1);
+        stage_run(ic<2>{}, ic<bwd_f0(2)>{}, ic<0>{}, ic<256>{}, A4, tiles_get(B), 7, a.dv0);
         // 3: views_linears.0[:, :256]^T + alpha_linear^T (d sigma as k-channel 128) -> delta of pts_linears.7 (mask a8)
         stage_run(ic<3>{}, ic<bwd_f0(3)>{}, ic<1>{}, ic<256>{}, B,
                   [&](auto G, auto J) {
@@ -291,15 +292,15 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
                       else if constexpr (g == 16 && j == 0) return h ? 0.0f : dsig;
                       else return 0.0f;
                   },
-                  act_row(kActA1 + 7, 256), a.da[7]);
+                  6, a.da[7]);
         finish_pass<kBwdHeadFrags, kBwdTrunk0>(ws);   // walk the padding up to the trunk stages
         // 4..9: pts_linears.7 .. .2 ^T in pairs (B -> A -> B), then pts_linears.1^T (last of the pass)
 #pragma unroll 1
         for (int l = 7; l >= 3; l -= 2) {
-            stage_run(ic<4>{}, ic<bwd_f0(4)>{}, ic<0>{}, ic<256>{}, A, tiles_get(B), act_row(kActA1 + l - 1, 256), a.da[l - 1]);
-            stage_run(ic<5>{}, ic<bwd_f0(5)>{}, ic<0>{}, ic<256>{}, B, tiles_get(A), act_row(kActA1 + l - 2, 256), a.da[l - 2]);
+            stage_run(ic<4>{}, ic<bwd_f0(4)>{}, ic<0>{}, ic<256>{}, A, tiles_get(B), l - 2, a.da[l - 1]);   // masks a_l: id l - 1; next: l - 2
+            stage_run(ic<5>{}, ic<bwd_f0(5)>{}, ic<0>{}, ic<256>{}, B, tiles_get(A), l - 3, a.da[l - 2]);   // masks a_(l-1): id l - 2; next: l - 3
         }
-        stage_run(ic<10>{}, ic<bwd_f0(10)>{}, ic<1>{}, ic<256>{}, A, tiles_get(B), act_row(kActA1 + 0, 256), a.da[0]);
+        stage_run(ic<10>{}, ic<bwd_f0(10)>{}, ic<1>{}, ic<256>{}, A, tiles_get(B), -1, a.da[0]);   // masks a1: id 0
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();

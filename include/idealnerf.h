@@ -257,7 +257,8 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream);
  * ------------------------------------------------------------------------------------------ */
 
 /* Floats of the activation slab idealnerf_query_rays_train_fwd fills for n_points points
- * (2560 columns x n_points rounded up to 128 rows; need not be initialised). */
+ * (2560 columns of saved activations + 88 floats of packed ReLU masks, x n_points rounded up to 128 rows;
+ * need not be initialised). */
 size_t idealnerf_train_acts_floats(int64_t n_points);
 
 /* idealnerf_query_rays_fwd that also records what the backward needs (the post-ReLU

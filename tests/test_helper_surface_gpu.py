@@ -362,3 +362,46 @@ def test_audio_nets_on_gpu_match_reference_and_conv_autograd(idn, dev, golden):
     with torch.no_grad():
         feats = clip_audio_features(aud_net.to(dev), att_net.to(dev), T(c["auds"]).to(dev))
     np.testing.assert_allclose(feats.cpu().numpy(), c["out"], rtol=2e-5, atol=2e-6)
+
+
+# --------------------------------------------------------------------------- BASELINE configs[3]: Obama, by name
+@pytest.mark.parametrize("cfg_name", ["NeRFs/HeadNeRF/configs/audio_expr_nerf/obama/paper_model.txt",
+                                      "NeRFs/HeadNeRF/configs/audio_expr_nerf/obama3/paper_model/torso_bg.txt",
+                                      "NeRFs/HeadNeRF/configs/audio_expr_nerf/obama3/paper_model_aud_only.txt"])
+def test_obama_configs_render_by_name(idn, dev, cfg_name):
+    """The reference's shipped Obama configs (their text is part of tests/golden/configs_parsed.json), parsed by
+    the product's config layer into the Network: near/far 0.567-0.634 / 1.167-1.234 and dim_expr 79 or 0 instead
+    of May's constants; a row band of the frame against the CPU oracle (the multi-GPU partition of configs[3])."""
+    import json, os
+    from idealnerf_amd import config
+    from idealnerf_amd.audio_exp_nerf import Network
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "configs_parsed.json")))[cfg_name]
+    ns = config.load_config(text="\n".join(gold["lines"]))
+    cfg = config.to_render_config(ns)
+    cfg.perturb = 0.0
+    assert (cfg.near, cfg.far) == (gold["parsed"]["near"], gold["parsed"]["far"]) and cfg.near != NEAR
+    H = W = 24
+    dims = oracle.facenerf_dims(dim_aud=cfg.dim_aud, dim_expr=cfg.dim_expr, dim_latent=cfg.dim_latent)
+    syn = oracle.synthetic_frame(H, W, seed=3, dims=dims)
+    net = Network(H, W, syn["focal"], cfg.near, cfg.far, cfg.chunk, None, cfg.N_samples, cfg.N_importance, args=cfg).to(dev).eval()
+    pc, pf = scale_sigma(oracle.xavier_facenerf_params(31, dims)), scale_sigma(oracle.xavier_facenerf_params(32, dims))
+    net.face_nerf_coarse.load_state_dict(pc)
+    net.face_nerf_fine.load_state_dict(pf)
+    g = lambda t: None if t is None else t.to(dev)
+    rows = (8, 14)     # rank 1's band of a 3-way split
+    with torch.no_grad():
+        rgb, disp, acc, last_w, extras = net.render_dynamic_face(
+            H, W, syn["focal"], expr=g(syn["expr"]) if cfg.dim_expr else None, poses=syn["c2w"], latent_code=g(syn["latent"]),
+            render_poses=syn["c2w"][:3, :4], chunk=cfg.chunk, near=cfg.near, far=cfg.far, bc_rgb=g(syn["bc"]),
+            aud_para=g(syn["aud"]), rows=rows)
+        ref = oracle.render_frame(H, W, syn["focal"], syn["c2w"], cfg.near, cfg.far, syn["bc"], pc, pf, syn["aud"],
+                                  syn["expr"] if cfg.dim_expr else None, syn["latent"], dims=dims, rows=rows)
+        ref64 = oracle.render_frame(H, W, syn["focal"], *oracle.to_f64((syn["c2w"], cfg.near, cfg.far, syn["bc"], pc, pf, syn["aud"],
+                                    syn["expr"] if cfg.dim_expr else None, syn["latent"])), dims=dims, rows=rows)
+    assert rgb.shape == (6, W, 3)
+    e32, e64 = rel_err(rgb, ref["rgb_map"]), rel_err(rgb, ref64["rgb_map"])
+    floor = oracle.fp32_noise_floor(ref["rgb_map"], ref64["rgb_map"])
+    assert e32 < RGB_TOL or e64 < max(RGB_TOL, 3.0 * floor), (e32, e64, floor)
+    assert rel_err(extras["rgb0"], ref["rgb0"]) < RGB_TOL
+    assert abs_err(last_w, ref["last_weight"]) < 10 * W_TOL

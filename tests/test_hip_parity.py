@@ -1228,8 +1228,20 @@ def test_train_forward_defines_every_row_of_the_activation_slab(idn, dev):
                                             z.data_ptr(), n, S, raw.data_ptr(), acts.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.idealnerf_last_error()
-    assert acts.numel() == 256 * 2560   # 185 points -> p_pad = 256 rows of 2560 columns
-    assert bool(torch.isfinite(acts).all()) and bool(torch.isfinite(raw).all())
+    assert acts.numel() == 256 * (2560 + 88)   # 185 points -> p_pad = 256 rows of 2560 columns + 88 floats of ReLU mask bits
+    assert bool(torch.isfinite(acts[:256 * 2560]).all()) and bool(torch.isfinite(raw).all())   # the tail is bit masks, not floats
+    # the packed ReLU masks say exactly which saved activations are positive: layer a3 (id 2), every point and channel
+    p_pad = 256
+    a3 = acts[(2 * 64 + 2 * 256) * p_pad:(2 * 64 + 3 * 256) * p_pad].reshape(p_pad, 256)            # x0, dir, a1, a2, then a3
+    words = acts[2560 * p_pad:].view(torch.int32).reshape(11, p_pad // 32, 64, 4)[2]                  # [wave tile, lane, dword]
+    pt = torch.arange(p_pad, device=dev)
+    for T_ in (0, 3, 7):
+        for r in (0, 5, 15):
+            for h_ in (0, 1):
+                ch = 32 * T_ + (r & 3) + 8 * (r >> 2) + 4 * h_
+                w = words[pt // 32, (pt % 32) + 32 * h_, T_ >> 1]
+                off = (w >> (31 - (16 * (T_ & 1) + r))) & 1
+                assert torch.equal(off == 0, a3[:, ch] > 0), (T_, r, h_)
 
 
 def test_head_torso_composite_bf16_modes_psnr(idn, dev):
