@@ -153,6 +153,9 @@ struct SaveSide {
     template <int T, int Q>
     __device__ __forceinline__ void rows_store(ic<T>, ic<Q>) const {
         asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));   // not before the wait that precedes this call
+#ifdef IDN_TIMING_NO_ROW_STORES   // timing-only experiment (wrong results): what do the row stores cost?
+        return;
+#endif
         static_for<4>([&](auto I) {
             constexpr int i = decltype(I)::value;
             // descriptor + one lane-offset VGPR + a compile-time scalar offset: no per-row address arithmetic or registers
@@ -161,6 +164,9 @@ struct SaveSide {
     }
     template <int T>
     __device__ __forceinline__ void flush_tile(ic<T>) const {   // outside the pair-step pipeline: explicit waits
+#ifdef IDN_TIMING_NO_FLUSH   // timing-only experiment (wrong results): what do the exposed layer-end flushes cost?
+        return;
+#endif
         scatter(ic<T>{});
         static_for<4>([&](auto Q) {
             rows_read(Q);

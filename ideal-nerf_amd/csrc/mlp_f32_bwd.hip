@@ -177,6 +177,9 @@ struct MaskSide {
     template <int T, int Q>
     __device__ __forceinline__ void rows_store(ic<T>, ic<Q>) const {
         asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));   // not before the wait that precedes this call
+#ifdef IDN_TIMING_NO_ROW_STORES   // timing-only experiment (wrong results): what do the row stores cost?
+        return;
+#endif
         static_for<4>([&](auto I) {
             constexpr int i = decltype(I)::value;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rb[i]), rsrc, voff, (2 * (4 * Q + i) * LD + 32 * T) * 4, 0);
@@ -184,6 +187,9 @@ struct MaskSide {
     }
     template <int T>
     __device__ __forceinline__ void flush_tile(ic<T>) const {   // outside the pair-step pipeline: explicit waits
+#ifdef IDN_TIMING_NO_FLUSH   // timing-only experiment (wrong results): what do the exposed layer-end flushes cost?
+        return;
+#endif
         scatter(ic<T>{});
         static_for<4>([&](auto Q) {
             rows_read(Q);
