@@ -400,8 +400,13 @@ def test_obama_configs_render_by_name(idn, dev, cfg_name):
         ref64 = oracle.render_frame(H, W, syn["focal"], *oracle.to_f64((syn["c2w"], cfg.near, cfg.far, syn["bc"], pc, pf, syn["aud"],
                                     syn["expr"] if cfg.dim_expr else None, syn["latent"])), dims=dims, rows=rows)
     assert rgb.shape == (6, W, 3)
-    e32, e64 = rel_err(rgb, ref["rgb_map"]), rel_err(rgb, ref64["rgb_map"])
-    floor = oracle.fp32_noise_floor(ref["rgb_map"], ref64["rgb_map"])
-    assert e32 < RGB_TOL or e64 < max(RGB_TOL, 3.0 * floor), (e32, e64, floor)
+
+    def ok(got, key, tol):
+        """within `tol` of the live fp32 oracle, or -- where the fp32 formula itself is that far from fp64 on this
+        scene -- within three times the oracle's own distance of the fp64 result (test_hip_parity.rgb_ok)"""
+        e32, e64 = rel_err(got, ref[key]), rel_err(got, ref64[key])
+        floor = oracle.fp32_noise_floor(ref[key], ref64[key])
+        return e32 < tol or e64 < max(tol, 3.0 * floor)
+
+    assert ok(rgb, "rgb_map", RGB_TOL) and ok(last_w, "last_weight", RGB_TOL)   # both behind the importance sampling
     assert rel_err(extras["rgb0"], ref["rgb0"]) < RGB_TOL
-    assert abs_err(last_w, ref["last_weight"]) < 10 * W_TOL
