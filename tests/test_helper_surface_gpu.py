@@ -401,12 +401,12 @@ def test_obama_configs_render_by_name(idn, dev, cfg_name):
                                     syn["expr"] if cfg.dim_expr else None, syn["latent"])), dims=dims, rows=rows)
     assert rgb.shape == (6, W, 3)
 
-    def ok(got, key, tol):
+    def ok(got, key, tol, err):
         """within `tol` of the live fp32 oracle, or -- where the fp32 formula itself is that far from fp64 on this
         scene -- within three times the oracle's own distance of the fp64 result (test_hip_parity.rgb_ok)"""
-        e32, e64 = rel_err(got, ref[key]), rel_err(got, ref64[key])
-        floor = oracle.fp32_noise_floor(ref[key], ref64[key])
+        e32, e64, floor = err(got, ref[key]), err(got, ref64[key]), err(ref[key], ref64[key])
         return e32 < tol or e64 < max(tol, 3.0 * floor)
 
-    assert ok(rgb, "rgb_map", RGB_TOL) and ok(last_w, "last_weight", RGB_TOL)   # both behind the importance sampling
+    # both sit behind the importance sampling; last_weight is bounded by 1 and may be ~1e-17: absolute error
+    assert ok(rgb, "rgb_map", RGB_TOL, rel_err) and ok(last_w, "last_weight", RGB_TOL, abs_err)
     assert rel_err(extras["rgb0"], ref["rgb0"]) < RGB_TOL
