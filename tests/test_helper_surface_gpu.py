@@ -410,3 +410,30 @@ def test_obama_configs_render_by_name(idn, dev, cfg_name):
     # both sit behind the importance sampling; last_weight is bounded by 1 and may be ~1e-17: absolute error
     assert ok(rgb, "rgb_map", RGB_TOL, rel_err) and ok(last_w, "last_weight", RGB_TOL, abs_err)
     assert rel_err(extras["rgb0"], ref["rgb0"]) < RGB_TOL
+
+
+# --------------------------------------------------------------------------- the driver's multi-GPU command, rehearsed
+def test_bench_two_ranks_from_a_plain_start(dev):
+    """`python bench.py --gpus 2 ...` as ONE plain process on this box: the launcher starts two ranks (sharing GPU 0
+    over gloo -- the one-GPU rehearsal of the RCCL path), each renders its row band, the tiles are all-gathered,
+    rank 0's line comes back.  Same kernels, same partition and the same code path as the 8-GPU run except for
+    the transport."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IDN_DIST_BACKEND="gloo", IDN_FORCE_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "96"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["backend"] == "gloo" and res["scaling"] == "strong"
+    assert res["config"]["band_rows"] == [48, 48] and res["steps"] == 2
+    assert res["value"] > 0 and res["roofline"]["frac"] is not None and res["roofline"]["traffic"] is None
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "96",
+                          "--no-cpu-baseline", "--no-side-mode"], env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][-1])
+    assert r1["n_gpus"] == 1 and r1["ranks"] == 1 and r1["config"]["rays_per_step"] == res["config"]["rays_per_step"]
