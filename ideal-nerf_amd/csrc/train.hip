@@ -146,8 +146,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     // A piece = 256 consecutive floats of a tile = 256 / BN rows of it.  Piece j (0 .. NTW-1) of wave w is
     // tile piece NTW * w + j: rows (NTW * w + j) * (256 / BN) ..; lane l moves float4 l of the piece.
     constexpr int kRowsPerPieceA = 256 / BN > 0 ? 256 / BN : 1, kRowsPerPieceB = 256 / BK > 0 ? 256 / BK : 1;
-    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + n0), 0, 0xfffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + k0), 0, 0xfffffffc, 0x00020000);
+    // descriptors based at this block's first row: the 32-bit piece offsets then span one split (tens of MB), not the
+    // whole matrix (which passes 4 GB from 4 M points on)
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + n0 + c_begin * kTnRows * (long)g.lda), 0, 0xfffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + k0 + c_begin * kTnRows * (long)g.ldb), 0, 0xfffffffc, 0x00020000);
     const uint32_t voffA = ((lane / (BN / 4)) * g.lda + (lane % (BN / 4)) * 4) * 4;
     const uint32_t voffB = ((lane / (BK / 4)) * g.ldb + (lane % (BK / 4)) * 4) * 4;
     const uint32_t rowA = g.lda * 4, rowB = g.ldb * 4;    // bytes per matrix row
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 #endif
         const int pc = NTW * w + ja;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(tn_smem + buf * kTileFloats + pc * 256), 16, voffA,
-                                                 (uint32_t)((c * kTnRows + pc * kRowsPerPieceA) * rowA), 0, 0);
+                                                 (uint32_t)(((c - c_begin) * kTnRows + pc * kRowsPerPieceA) * rowA), 0, 0);
     };
     auto piece_b = [&](long c, int buf, int jb) {
 #ifdef IDN_TN_TIMING_NO_PIECES
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 #endif
         const int pc = KTW * w + jb;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(tn_smem + buf * kTileFloats + kTnRows * BN + pc * 256), 16, voffB,
-                                                 (uint32_t)((c * kTnRows + pc * kRowsPerPieceB) * rowB), 0, 0);
+                                                 (uint32_t)(((c - c_begin) * kTnRows + pc * kRowsPerPieceB) * rowB), 0, 0);
     };
     auto piece = [&](long c, int buf, int j) {   // prologue order: A pieces, then B pieces
         if (j < NTW) piece_a(c, buf, j);
