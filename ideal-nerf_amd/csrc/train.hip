@@ -536,7 +536,7 @@ __global__ void fold_bwd_kernel(FoldBwdArgs d) {
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kMaxSplits = 256;
 constexpr int kColsumBlocks = 256;   // rows of the column-sum partial buffer (>= kMaxSplits)
-constexpr int kGemmsPerPass = 14;
+constexpr int kGemmsPerPass = 16;
 // partial-slab floats of one split over all GEMMs of a pass: 8 of 256x256, 3 of 256x64, 2 of 128x128, 1 of 64x128
 constexpr size_t kPartFloatsPerSplit = 8 * 65536 + 3 * 16384 + 2 * 16384 + 8192;
 
@@ -575,6 +575,8 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
     int ntw, ktw;
     if (N == 256 && K == 256) { ntw = 4; ktw = 4; }
     else if (N == 256 && K == 64) { ntw = 4; ktw = 1; }
+    else if (N == 128 && K == 256) { ntw = 2; ktw = 4; }   // views_linears.0: its 128 units x the 256 trunk channels
+    else if (N == 128 && K == 64) { ntw = 2; ktw = 1; }    //                  ... x the direction encoding
     else if (N == 128 && K == 128) { ntw = 2; ktw = 2; }
     else if (N == 64 && K == 128) { ntw = 1; ktw = 2; }
     else return fail(IDN_EUNSUPPORTED, "gemm_tn: no instantiation for %d x %d", N, K);
@@ -595,18 +597,85 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kTnBufs * kTnRows * 512 * 4));
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<4, 1>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kTnBufs * kTnRows * 320 * 4));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<2, 4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kTnBufs * kTnRows * 384 * 4));
             return IDN_OK;
         }, &num_cu))
         return e;
     ProfScope prof(s, P, IDN_PROF_DW_GEMM);
     if (ntw == 4 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, lds, s, g);
     else if (ntw == 4 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), grid, block, lds, s, g);
+    else if (ntw == 2 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<2, 4>), grid, block, lds, s, g);
+    else if (ntw == 2 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<2, 1>), grid, block, lds, s, g);
     else if (ntw == 2 && ktw == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, lds, s, g);
     else hipLaunchKernelGGL((gemm_tn_kernel<1, 2>), grid, block, lds, s, g);
     IDN_HIP_CHECK(hipGetLastError());
     *splits_out = splits;
     return IDN_OK;
 }
+// part[b][k] = sum over block b's rows of w[row] * B[row][k] (k < 256), partw[b] = sum of w[row]: the gradient of a
+// single output unit fed by B -- alpha_linear, whose delta (d sigma) is one column.  It used to ride as channel 128
+// of views_linears.0's 256-wide delta matrix, which made that layer's dW GEMMs 256 rows tall for 129 used.
+constexpr int kWsumBlocks = 1024;   // 4 per CU: the kernel is a latency-bound stream (1 KiB of B per row)
+__global__ __launch_bounds__(256) void wsum_kernel(const float* __restrict__ w, int wld, const float* __restrict__ B, int ldb,
+                                                   long P, float* __restrict__ part, float* __restrict__ partw) {
+    // wave v of the block takes rows r0 + v, r0 + v + 4, ...; lane l the four columns 4 l .. 4 l + 3 (one dwordx4 per row)
+    __shared__ f32x4 red[4][64];
+    __shared__ float redw[4];
+    const long rows = (P + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rows;
+    long r1 = r0 + rows;
+    if (r1 > P) r1 = P;
+    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
+    f32x4 s[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float sw = 0.f;
+    long r = r0 + v;
+    for (; r + 12 < r1; r += 16) {   // four rows of this wave in flight
+        float wv[4];
+        f32x4 bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            wv[u] = w[(r + 4 * u) * wld];
+            bv[u] = *reinterpret_cast<const f32x4*>(B + (r + 4 * u) * ldb + 4 * lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[u].x = fmaf(wv[u], bv[u].x, s[u].x);
+            s[u].y = fmaf(wv[u], bv[u].y, s[u].y);
+            s[u].z = fmaf(wv[u], bv[u].z, s[u].z);
+            s[u].w = fmaf(wv[u], bv[u].w, s[u].w);
+            sw += wv[u];
+        }
+    }
+    for (; r < r1; r += 4) {
+        const float w0 = w[r * wld];
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(B + r * ldb + 4 * lane);
+        s[0].x = fmaf(w0, b0.x, s[0].x);
+        s[0].y = fmaf(w0, b0.y, s[0].y);
+        s[0].z = fmaf(w0, b0.z, s[0].z);
+        s[0].w = fmaf(w0, b0.w, s[0].w);
+        sw += w0;
+    }
+    f32x4 t;
+    t.x = (s[0].x + s[1].x) + (s[2].x + s[3].x);
+    t.y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+    t.z = (s[0].z + s[1].z) + (s[2].z + s[3].z);
+    t.w = (s[0].w + s[1].w) + (s[2].w + s[3].w);
+    red[v][lane] = t;
+    if (lane == 0) redw[v] = sw;
+    __syncthreads();
+    if (v == 0) {
+        const f32x4 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
+        f32x4 o;
+        o.x = (a.x + b.x) + (c.x + d.x);
+        o.y = (a.y + b.y) + (c.y + d.y);
+        o.z = (a.z + b.z) + (c.z + d.z);
+        o.w = (a.w + b.w) + (c.w + d.w);
+        *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * 256 + 4 * lane) = o;
+        if (lane == 0) partw[blockIdx.x] = (redw[0] + redw[1]) + (redw[2] + redw[3]);
+    }
+}
+
 // The reductions of a pass are queued and launched together (flush) once every GEMM has been issued.
 struct ReduceQueue {
     ReduceBatch b;
@@ -670,7 +739,9 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
 
     // d(outputs) -> d raw, written straight into the head deltas (zero elsewhere)
     IDN_HIP_CHECK(hipMemsetAsync(w.dRGB, 0, (size_t)Pp * 64 * 4, s));
-    IDN_HIP_CHECK(hipMemsetAsync(w.dV0, 0, (size_t)Pp * 256 * 4, s));
+    // dV0: columns 0..127 are written by the delta chain for every row, column 128 (d sigma) by the compositing
+    // backward for every real point; only the padding rows of that column need zeros (the other columns are not read)
+    if (Pp > P) IDN_HIP_CHECK(hipMemsetAsync(w.dV0 + (size_t)P * 256, 0, (size_t)(Pp - P) * 256 * 4, s));
     {
         CompBwdArgs a{reinterpret_cast<const float4*>(raw), z, rays, bc, g_rgb, g_fg, g_lw, g_acc,
                       w.dRGB, 64, w.dV0 + kSigmaChannel, 256, (long)n_rays, S};
@@ -693,17 +764,19 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
     TRY(run_tn(q, w.dRGB, 64, 64, v_l(3), 128, 128, Pp, gr.rgb_w, 128, 3, 128, s, gr.rgb_b, 3));
     TRY(run_tn(q, w.dV[0], 128, 128, v_l(2), 128, 128, Pp, gr.views_w[2], 128, 128, 128, s, gr.views_b[2], 128));
     TRY(run_tn(q, w.dV[1], 128, 128, v_l(1), 128, 128, Pp, gr.views_w[1], 128, 128, 128, s, gr.views_b[1], 128));
-    // views_linears.0 (+ alpha_linear as channel 128); inputs [a8 | dirPE | expr(folded)]
+    // views_linears.0: its 128 units against [a8 | dirPE] (the expr columns are folded); alpha_linear, whose delta is the
+    // single column d sigma (dV0[:, 128]), as a weighted column sum of a8
+    TRY(run_tn(q, w.dV0, 256, 128, a_l(8), 256, 256, Pp, gr.views_w[0], ldv, 128, 256, s, gr.views_b[0], 128));
+    TRY(run_tn(q, w.dV0, 256, 128, act(kActDir), 64, 64, Pp, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH, s));
     {
-        int splits = 0;
-        const float *part, *cpart;
-        TRY(run_tn_q(q, w.dV0, 256, 256, a_l(8), 256, 256, Pp, &splits, &part, &cpart, true, s));
-        TRY(q.add(cpart, splits, 1, 256, 0, 0, gr.views_b[0], 256, 1, 128));
-        TRY(q.add(cpart, splits, 1, 256, 0, kSigmaChannel, gr.alpha_b, 256, 1, 1));
-        TRY(q.add(part, splits, 256, 256, 0, 0, gr.views_w[0], ldv, 128, 256));
-        TRY(q.add(part, splits, 256, 256, kSigmaChannel, 0, gr.alpha_w, 256, 1, 256));
-        TRY(run_tn_q(q, w.dV0, 256, 256, act(kActDir), 64, 64, Pp, &splits, &part, nullptr, false, s));
-        TRY(q.add(part, splits, 256, 64, 0, 0, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH));
+        float* part = q.part_next;
+        float* partw = q.cpart_next;
+        q.part_next += (size_t)kWsumBlocks * 256;
+        q.cpart_next += kWsumBlocks;
+        hipLaunchKernelGGL(wsum_kernel, dim3(kWsumBlocks), dim3(256), 0, s, w.dV0 + kSigmaChannel, 256, a_l(8), 256, (long)Pp, part, partw);
+        IDN_HIP_CHECK(hipGetLastError());
+        TRY(q.add(part, kWsumBlocks, 1, 256, 0, 0, gr.alpha_w, 256, 1, 256));
+        TRY(q.add(partw, kWsumBlocks, 1, 1, 0, 0, gr.alpha_b, 1, 1, 1));
     }
     for (int l = 7; l >= 1; --l) {
         const float* cur = w.dA[l];
