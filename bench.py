@@ -78,11 +78,12 @@ def launch_ranks(n, argv, script=None, timeout=None):
     line = None
     for ln in proc.stdout.splitlines():
         try:
-            if "metric" in json.loads(ln):
-                line = ln
-                continue
+            obj = json.loads(ln)
         except ValueError:
-            pass
+            obj = None
+        if isinstance(obj, dict) and "metric" in obj:   # (a stray "1" from a rank's log is valid JSON too)
+            line = ln
+            continue
         sys.stderr.write(ln + "\n")      # anything else the ranks printed is diagnostics
     if proc.returncode != 0:
         sys.stderr.write(f"bench.py: a rank failed (torch.distributed.run exit code {proc.returncode})\n")

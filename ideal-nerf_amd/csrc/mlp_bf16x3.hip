@@ -338,41 +338,52 @@ __device__ __forceinline__ void convert_words_plain(const f32x16& acc, PTile& ou
         if constexpr (w < 8) convert_word_plain<w, RELU>(acc, out);
     });
 }
-template <int NT, int STEPS, bool DEFER>
+// PT point sets (32 points each) per wave share every weight fragment: the layer's MFMAs go
+// (fragment, set 0), (fragment, set 1), ... so a ds_read_b128 feeds PT MFMAs.  At PT = 1 every
+// 32-cycle MFMA needs its own 1 KiB fragment: 4 SIMDs x 32 B/cycle = the LDS's whole 128 B/cycle.
+template <int NT, int STEPS, bool DEFER, int PT, class Out, class Def>
 struct SidePlain {
-    PTile* out;
-    PTile* deferred;
-    f32x16* pend;
-    f32x16* acc;
+    Out out;            // out(ic<q>) -> PTile* of set q
+    Def deferred;       // deferred(ic<q>) -> PTile* (the previous layer's last tile of set q)
+    f32x16* pend;       // pend[PT]
+    f32x16 (*acc)[2];   // acc[PT][2]
     const float* bias_half;
     template <int T, int S, int H>
     __device__ __forceinline__ void operator()(ic<T>, ic<S>, ic<H>) const {
         constexpr int C = (8 + STEPS - 1) / STEPS;
         constexpr int CD = (16 + STEPS - 1) / STEPS;  // deferred tile: done by STEPS/2, ahead of its first use
-        if constexpr (H == 0) {
-            if constexpr (T > 0) convert_words_plain<S * C, C, true>(*pend, out[T - 1]);
-            if constexpr (T == 0 && DEFER) convert_words_plain<S * CD, CD, true>(*pend, *deferred);
-        } else {
-            // the next tile's bias: 4 quads spread over the pair-steps (2 per step when STEPS == 2)
-            constexpr int QB = (4 + STEPS - 1) / STEPS;
-            if constexpr (T + 1 < NT)
-                static_for<QB>([&](auto Q_) {
-                    constexpr int q = S * QB + decltype(Q_)::value;
-                    if constexpr (q < 4) bias_quad<q>(acc[(T + 1) & 1], bias_half + 32 * (T + 1));
-                });
-        }
+        static_for<PT>([&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            if constexpr (H == 0) {
+                if constexpr (T > 0) convert_words_plain<S * C, C, true>(pend[q], out(ic<q>{})[T - 1]);
+                if constexpr (T == 0 && DEFER) convert_words_plain<S * CD, CD, true>(pend[q], *deferred(ic<q>{}));
+            } else {
+                // the next tile's bias: 4 quads spread over the pair-steps (2 per step when STEPS == 2)
+                constexpr int QB = (4 + STEPS - 1) / STEPS;
+                if constexpr (T + 1 < NT)
+                    static_for<QB>([&](auto B_) {
+                        constexpr int b = S * QB + decltype(B_)::value;
+                        if constexpr (b < 4) bias_quad<b>(acc[q][(T + 1) & 1], bias_half + 32 * (T + 1));
+                    });
+            }
+        });
     }
 };
 
-template <int F0, int NT, int KS, bool DEFER, class BGet, class WS, class Hook = NoHook>
-__device__ __forceinline__ void run_layer_plain(PTile* out, PTile* deferred, f32x16& pend, f32x16 (&acc)[2],
+struct NoDeferred {
+    template <int Q>
+    __device__ __forceinline__ PTile* operator()(ic<Q>) const { return nullptr; }
+};
+
+template <int F0, int NT, int KS, bool DEFER, int PT, class Out, class Def, class BGet, class WS, class Hook = NoHook>
+__device__ __forceinline__ void run_layer_plain(Out&& out, Def&& deferred, f32x16 (&pend)[PT], f32x16 (&acc)[PT][2],
                                                 const float* bias_half, BGet&& bget, WS& ws, FragReader& fr,
                                                 Hook&& after_open = NoHook{}) {
     constexpr int STEPS = KS / 2, NP = NT * STEPS;
     constexpr bool LAST = (F0 + NT * KS == kPlainUsedFrags);
     static_assert(F0 % 2 == 0 && KS % 2 == 0, "k-steps are consumed in pairs");
-    bias_tile(acc[0], bias_half);
-    const SidePlain<NT, STEPS, DEFER> side{out, deferred, &pend, &acc[0], bias_half};
+    static_for<PT>([&](auto Q_) { bias_tile(acc[decltype(Q_)::value][0], bias_half); });
+    const SidePlain<NT, STEPS, DEFER, PT, std::decay_t<Out>, std::decay_t<Def>> side{out, deferred, &pend[0], &acc[0], bias_half};
     if constexpr (F0 % kSliceFrags == 0) {
         ws.open_slice();
         after_open();
@@ -396,11 +407,17 @@ __device__ __forceinline__ void run_layer_plain(PTile* out, PTile* deferred, f32
             FragReader::retire<0>(a0, a1);
         }
         ws.template step_piece<f>();
-        acc[t & 1] = mfma_bf(a0, bget(ic<2 * s>{}), acc[t & 1]);
+        static_for<PT>([&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            acc[q][t & 1] = mfma_bf(a0, bget(ic<q>{}, ic<2 * s>{}), acc[q][t & 1]);
+        });
         side(ic<t>{}, ic<s>{}, ic<0>{});
-        acc[t & 1] = mfma_bf(a1, bget(ic<2 * s + 1>{}), acc[t & 1]);
+        static_for<PT>([&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            acc[q][t & 1] = mfma_bf(a1, bget(ic<q>{}, ic<2 * s + 1>{}), acc[q][t & 1]);
+        });
         side(ic<t>{}, ic<s>{}, ic<1>{});
-        if constexpr (s == STEPS - 1) pend = acc[t & 1];
+        if constexpr (s == STEPS - 1) static_for<PT>([&](auto Q_) { pend[decltype(Q_)::value] = acc[decltype(Q_)::value][t & 1]; });
         if constexpr (next_crosses && pi + 1 < NP) {
             ws.open_slice();
             n0 = fr.template issue<f + 2>();
@@ -413,12 +430,14 @@ __device__ __forceinline__ void run_layer_plain(PTile* out, PTile* deferred, f32
     fr.pref1 = a1;
 }
 
-// NW waves per workgroup (32 NW points per pass).  NW = 8 puts two waves on each SIMD: the kernel
-// fits 256 registers in this mode (a few spills), one wave's conversions / encoding / piece issue
-// then run in the shadow of the other wave's MFMAs, and a pass streams the weights once per 256
-// points.  Same-box A/B against NW = 4: +14 %.  The accumulators then live in VGPRs, so nothing
-// that reads an MFMA result may be inline asm (the hazard recogniser does not look inside).
-template <int MODE, int NW>
+// NW waves per workgroup, PT point sets of 32 points per wave (32 NW PT points per pass).
+//   NW = 8, PT = 1: two waves on each SIMD; the kernel fits 256 registers in this mode (a few spills), one
+//     wave's conversions / encoding / piece issue run in the shadow of the other wave's MFMAs.  Same-box A/B
+//     against NW = 4, PT = 1: +14 %.  The accumulators then live in VGPRs, so nothing that reads an MFMA
+//     result may be inline asm (the hazard recogniser does not look inside).
+//   NW = 4, PT = 2: one wave per SIMD with 512 registers; every weight fragment read from LDS feeds two
+//     MFMAs (see SidePlain), and two independent accumulators alternate on the pipe.
+template <int MODE, int NW, int PT>
 __global__ __launch_bounds__(64 * NW, 1) void mlp_bf16_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
@@ -440,17 +459,20 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_bf16_kernel(MlpArgs a) {
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
     fr.addr1 = fr.addr0 + 64 * kFragBytes;
     const float* bias_h = bias_s + 4 * h;
-    constexpr int kTilePts = 32 * NW;
+    constexpr int kSets = NW * PT;            // 32-point sets per pass; wave w owns sets w PT .. w PT + PT - 1
+    constexpr int kTilePts = 32 * kSets;
     const long ntiles = (a.n_points + kTilePts - 1) / kTilePts;
 
-    PointIn cur, nxt;
-    load_point<MODE, NW>(a, blockIdx.x, wave, m, cur);
-    nxt = cur;
+    PointIn cur[PT], nxt[PT];
+    static_for<PT>([&](auto Q_) {
+        constexpr int q = decltype(Q_)::value;
+        load_point<MODE, kSets>(a, blockIdx.x, wave * PT + q, m, cur[q]);
+        nxt[q] = cur[q];
+    });
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long P = tile * kTilePts + wave * 32 + m;
-        const bool valid = P < a.n_points;
-        const long Pc = valid ? P : a.n_points - 1;
-        f32x4 pe_v[4], pd_v[2];
+        long P[PT];
+        bool valid[PT];
+        f32x4 pe_v[PT][4], pd_v[PT][2];
         auto pack_feats = [&](auto&& feat, f32x4* o, auto NKS) {
             static_for<decltype(NKS)::value>([&](auto S_) {
                 constexpr int s = decltype(S_)::value;
@@ -462,50 +484,78 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_bf16_kernel(MlpArgs a) {
                 });
             });
         };
-        input_features<MODE>(a, Pc, h, pln, cur, [&](auto&& fpt, auto&& fdir) {
-            pack_feats(fpt, pe_v, ic<4>{});
-            pack_feats(fdir, pd_v, ic<2>{});
+        static_for<PT>([&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            P[q] = tile * kTilePts + (wave * PT + q) * 32 + m;
+            valid[q] = P[q] < a.n_points;
+            const long Pc = valid[q] ? P[q] : a.n_points - 1;
+            input_features<MODE>(a, Pc, h, pln, cur[q], [&](auto&& fpt, auto&& fdir) {
+                pack_feats(fpt, pe_v[q], ic<4>{});
+                pack_feats(fdir, pd_v[q], ic<2>{});
+            });
         });
 
-        PTile A[8], B[8], V[4], Vx[5], none[1];
-        f32x16 acc[2], pend;
-        auto tiles = [](PTile* arr) { return [arr](auto S_) { constexpr int s = decltype(S_)::value; return arr[s >> 1].v[s & 1]; }; };
-        auto pe_g = [&](auto S_) { return pe_v[decltype(S_)::value]; };
+        PTile A[PT][8], B[PT][8], V[PT][4], Vx[PT][5], none[PT][1];
+        f32x16 acc[PT][2], pend[PT];
+        // providers: set q's tile array / one tile of it / k-step s of its packed activations
+        auto set_of = [](auto* arr) { return [arr](auto Q_) { return &arr[decltype(Q_)::value][0]; }; };
+        auto last_of = [](auto* arr, auto T_) { return [arr](auto Q_) { return &arr[decltype(Q_)::value][decltype(T_)::value]; }; };
+        auto tiles = [](auto* arr) {
+            return [arr](auto Q_, auto S_) { constexpr int s = decltype(S_)::value; return arr[decltype(Q_)::value][s >> 1].v[s & 1]; };
+        };
+        auto pe_g = [&](auto Q_, auto S_) { return pe_v[decltype(Q_)::value][decltype(S_)::value]; };
 
-        run_layer_plain<plain_f0(0), 8, 4, false>(A, nullptr, pend, acc, bias_h + bias_off(0), pe_g, ws, fr);
+        run_layer_plain<plain_f0(0), 8, 4, false, PT>(set_of(A), NoDeferred{}, pend, acc, bias_h + bias_off(0), pe_g, ws, fr);
 #pragma unroll 1
         for (int l = 1; l <= 3; l += 2) {
-            run_layer_plain<plain_f0(1), 8, 16, true>(B, &A[7], pend, acc, bias_h + l * 256, tiles(A), ws, fr);
-            run_layer_plain<plain_f0(2), 8, 16, true>(A, &B[7], pend, acc, bias_h + (l + 1) * 256, tiles(B), ws, fr);
+            run_layer_plain<plain_f0(1), 8, 16, true, PT>(set_of(B), last_of(A, ic<7>{}), pend, acc, bias_h + l * 256, tiles(A), ws, fr);
+            run_layer_plain<plain_f0(2), 8, 16, true, PT>(set_of(A), last_of(B, ic<7>{}), pend, acc, bias_h + (l + 1) * 256, tiles(B), ws, fr);
         }
-        run_layer_plain<plain_f0(5), 8, 20, true>(
-            B, &A[7], pend, acc, bias_h + bias_off(5),
-            [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 4) return pe_v[s]; else return A[(s - 4) >> 1].v[(s - 4) & 1]; },
+        run_layer_plain<plain_f0(5), 8, 20, true, PT>(
+            set_of(B), last_of(A, ic<7>{}), pend, acc, bias_h + bias_off(5),
+            [&](auto Q_, auto S_) {
+                constexpr int q = decltype(Q_)::value, s = decltype(S_)::value;
+                if constexpr (s < 4) return pe_v[q][s]; else return A[q][(s - 4) >> 1].v[(s - 4) & 1];
+            },
             ws, fr);
-        run_layer_plain<plain_f0(6), 8, 16, true>(A, &B[7], pend, acc, bias_h + bias_off(6), tiles(B), ws, fr,
-                                                  [&]() { load_point<MODE, NW>(a, tile + gridDim.x, wave, m, nxt); });
-        run_layer_plain<plain_f0(7), 8, 16, true>(B, &A[7], pend, acc, bias_h + bias_off(7), tiles(A), ws, fr,
-                                                  [&]() { touch_point(nxt); });
-        run_layer_plain<plain_f0(8), 5, 18, true>(
-            Vx, &B[7], pend, acc, bias_h + bias_off(8),
-            [&](auto S_) { constexpr int s = decltype(S_)::value; if constexpr (s < 16) return B[s >> 1].v[s & 1]; else return pd_v[s - 16]; },
+        run_layer_plain<plain_f0(6), 8, 16, true, PT>(set_of(A), last_of(B, ic<7>{}), pend, acc, bias_h + bias_off(6), tiles(B), ws, fr, [&]() {
+            static_for<PT>([&](auto Q_) {
+                constexpr int q = decltype(Q_)::value;
+                load_point<MODE, kSets>(a, tile + gridDim.x, wave * PT + q, m, nxt[q]);
+            });
+        });
+        run_layer_plain<plain_f0(7), 8, 16, true, PT>(set_of(B), last_of(A, ic<7>{}), pend, acc, bias_h + bias_off(7), tiles(A), ws, fr,
+                                                      [&]() { static_for<PT>([&](auto Q_) { touch_point(nxt[decltype(Q_)::value]); }); });
+        run_layer_plain<plain_f0(8), 5, 18, true, PT>(
+            set_of(Vx), last_of(B, ic<7>{}), pend, acc, bias_h + bias_off(8),
+            [&](auto Q_, auto S_) {
+                constexpr int q = decltype(Q_)::value, s = decltype(S_)::value;
+                if constexpr (s < 16) return B[q][s >> 1].v[s & 1]; else return pd_v[q][s - 16];
+            },
             ws, fr);
-        const float sigma = pend[0];
-        static_for<4>([&](auto T) { V[decltype(T)::value] = Vx[decltype(T)::value]; });
-        run_layer_plain<plain_f0(9), 4, 8, false>(A, nullptr, pend, acc, bias_h + bias_off(9), tiles(V), ws, fr);
-        run_layer_plain<plain_f0(10), 4, 8, true>(V, &A[3], pend, acc, bias_h + bias_off(10), tiles(A), ws, fr);
-        run_layer_plain<plain_f0(11), 1, 8, true>(none, &V[3], pend, acc, bias_h + bias_off(11), tiles(V), ws, fr);
+        float sigma[PT];
+        static_for<PT>([&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            sigma[q] = pend[q][0];
+            static_for<4>([&](auto T) { V[q][decltype(T)::value] = Vx[q][decltype(T)::value]; });
+        });
+        run_layer_plain<plain_f0(9), 4, 8, false, PT>(set_of(A), NoDeferred{}, pend, acc, bias_h + bias_off(9), tiles(V), ws, fr);
+        run_layer_plain<plain_f0(10), 4, 8, true, PT>(set_of(V), last_of(A, ic<3>{}), pend, acc, bias_h + bias_off(10), tiles(A), ws, fr);
+        run_layer_plain<plain_f0(11), 1, 8, true, PT>(set_of(none), last_of(V, ic<3>{}), pend, acc, bias_h + bias_off(11), tiles(V), ws, fr);
         finish_pass<kPlainUsedFrags, kPlainStreamFrags>(ws);
 
-        if (valid && h == 0) {
-            f32x4 o;
-            o.x = pend[0];
-            o.y = pend[1];
-            o.z = pend[2];
-            o.w = sigma;
-            *reinterpret_cast<f32x4*>(a.raw + P * 4) = o;
-        }
-        cur = nxt;
+        static_for<PT>([&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            if (valid[q] && h == 0) {
+                f32x4 o;
+                o.x = pend[q][0];
+                o.y = pend[q][1];
+                o.z = pend[q][2];
+                o.w = sigma[q];
+                *reinterpret_cast<f32x4*>(a.raw + P[q] * 4) = o;
+            }
+            cur[q] = nxt[q];
+        });
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -514,32 +564,35 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_bf16_kernel(MlpArgs a) {
 #ifndef IDN_PLAIN_WAVES
 #define IDN_PLAIN_WAVES 8
 #endif
+#ifndef IDN_PLAIN_SETS
+#define IDN_PLAIN_SETS 1
+#endif
 int launch_mlp_bf16(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
                     const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s) {
-    constexpr int NW = IDN_PLAIN_WAVES;
+    constexpr int NW = IDN_PLAIN_WAVES, PT = IDN_PLAIN_SETS;
     if (n_points <= 0) return IDN_OK;
     static LaunchSetup setup;
     int num_cu = 0;
     if (int e = setup.get([]() -> int {
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModeRays, NW>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModeRays, NW, PT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModeX, NW>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModeX, NW, PT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModePts, NW>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bf16_kernel<kModePts, NW, PT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
             return IDN_OK;
         }, &num_cu))
         return e;
-    const int64_t ntiles = (n_points + 32 * NW - 1) / (32 * NW);
+    const int64_t ntiles = (n_points + 32 * NW * PT - 1) / (32 * NW * PT);
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, nullptr, 0};
     ProfScope prof(s, n_points);
     if (x)
-        hipLaunchKernelGGL((mlp_bf16_kernel<kModeX, NW>), dim3(grid), dim3(64 * NW), kMlpLds, s, a);
+        hipLaunchKernelGGL((mlp_bf16_kernel<kModeX, NW, PT>), dim3(grid), dim3(64 * NW), kMlpLds, s, a);
     else if (pts)
-        hipLaunchKernelGGL((mlp_bf16_kernel<kModePts, NW>), dim3(grid), dim3(64 * NW), kMlpLds, s, a);
+        hipLaunchKernelGGL((mlp_bf16_kernel<kModePts, NW, PT>), dim3(grid), dim3(64 * NW), kMlpLds, s, a);
     else
-        hipLaunchKernelGGL((mlp_bf16_kernel<kModeRays, NW>), dim3(grid), dim3(64 * NW), kMlpLds, s, a);
+        hipLaunchKernelGGL((mlp_bf16_kernel<kModeRays, NW, PT>), dim3(grid), dim3(64 * NW), kMlpLds, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

@@ -496,11 +496,12 @@ def test_bench_launcher_propagates_a_failed_rank(tmp_path, capsys):
     good = tmp_path / "good_rank.py"
     good.write_text("import os, sys, json\n"
                     "assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                    "print('1')\nprint('[3]')\nprint('\"metric\"')\n"   # log fragments that happen to be valid JSON
                     "if os.environ['RANK'] == '0':\n"
                     "    print(json.dumps({'metric': 'm', 'value': 2.0, 'argv': sys.argv[1:]}))\n")
     rc = bench.launch_ranks(2, ["--steps", "4"], script=str(good), timeout=300)
     out = capsys.readouterr()
-    assert rc == 0
+    assert rc == 0 and len(out.out.strip().splitlines()) == 1
     import json
     assert json.loads(out.out.strip())["argv"] == ["--steps", "4"]
 
