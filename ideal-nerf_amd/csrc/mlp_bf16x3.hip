@@ -228,6 +228,9 @@ __global__ __launch_bounds__(256, 1) void X3_KERNEL(MlpArgs a) {
     PointIn cur, nxt;
     load_point<MODE>(a, blockIdx.x, wave, m, cur);
     nxt = cur;
+#ifdef IDN_TIMING_PE_ONCE
+    f32x4 pe_hi[4], pe_lo[4], pd_hi[2], pd_lo[2];
+#endif
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long P = tile * 128 + wave * 32 + m;
         const bool valid = P < a.n_points;
@@ -235,7 +238,10 @@ __global__ __launch_bounds__(256, 1) void X3_KERNEL(MlpArgs a) {
 
         // ---- inputs: this lane's half of the 64 point features and 32 direction features.
         // Element j of k-step s, lane half h = feature 16s + (j&3) + 8(j>>2) + 4h.
+#ifdef IDN_TIMING_PE_ONCE   // timing-only (wrong results): the encoding of the block's first tile serves every pass
+#else
         f32x4 pe_hi[4], pe_lo[4], pd_hi[2], pd_lo[2];
+#endif
         auto pack_feats = [&](auto&& feat, f32x4* ohi, f32x4* olo, auto NKS) {
             static_for<decltype(NKS)::value>([&](auto S_) {
                 constexpr int s = decltype(S_)::value;
@@ -250,6 +256,9 @@ __global__ __launch_bounds__(256, 1) void X3_KERNEL(MlpArgs a) {
                 });
             });
         };
+#ifdef IDN_TIMING_PE_ONCE
+        if (tile == blockIdx.x)
+#endif
         input_features<MODE>(a, Pc, h, pln, cur, [&](auto&& fpt, auto&& fdir) {
             pack_feats(fpt, pe_hi, pe_lo, ic<4>{});
             pack_feats(fdir, pd_hi, pd_lo, ic<2>{});
@@ -469,10 +478,15 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_bf16_kernel(MlpArgs a) {
         load_point<MODE, kSets>(a, blockIdx.x, wave * PT + q, m, cur[q]);
         nxt[q] = cur[q];
     });
+#ifdef IDN_TIMING_PE_ONCE   // timing-only (wrong results): the encoding of the block's first tile serves every pass
+    f32x4 pe_v[PT][4], pd_v[PT][2];
+#endif
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         long P[PT];
         bool valid[PT];
+#ifndef IDN_TIMING_PE_ONCE
         f32x4 pe_v[PT][4], pd_v[PT][2];
+#endif
         auto pack_feats = [&](auto&& feat, f32x4* o, auto NKS) {
             static_for<decltype(NKS)::value>([&](auto S_) {
                 constexpr int s = decltype(S_)::value;
@@ -489,6 +503,9 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_bf16_kernel(MlpArgs a) {
             P[q] = tile * kTilePts + (wave * PT + q) * 32 + m;
             valid[q] = P[q] < a.n_points;
             const long Pc = valid[q] ? P[q] : a.n_points - 1;
+#ifdef IDN_TIMING_PE_ONCE
+            if (tile == blockIdx.x)
+#endif
             input_features<MODE>(a, Pc, h, pln, cur[q], [&](auto&& fpt, auto&& fdir) {
                 pack_feats(fpt, pe_v[q], ic<4>{});
                 pack_feats(fdir, pd_v[q], ic<2>{});

@@ -102,6 +102,9 @@ __device__ __forceinline__ void tn_static_for(F&& f) {
 // row offset (half the issue cost of the per-lane-pointer form), and they have a whole chunk to land: the
 // GEMM reads 2 KiB per point and layer for 131 kFLOP, i.e. it needs 2.5 TB/s of HBM at the MFMA peak.
 constexpr int kTnRows = 16, kTnBufs = 3;
+#ifndef IDN_DW_X6
+#define IDN_DW_X6 1    // 256 x 256 dW GEMMs as six bf16 piece products (gemm_tn_x6_kernel); 0: the fp32-MFMA kernel
+#endif
 
 #ifdef IDN_DIAG   // diagnostic build only: where a <4,4> block spends its cycles (tools/diag_tn.py)
 __device__ unsigned long long g_tn_diag[8];   // total, wait (vmcnt + barrier), loop, epilogue, blocks, chunks
@@ -304,6 +307,193 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
         atomicAdd(&g_tn_diag[5], (unsigned long long)(c_end - c_begin));
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// The 256 x 256 dW GEMMs on the bf16 matrix pipe: every fp32 operand is the exact sum of three bf16 pieces
+// (x = p1 + p2 + p3, each the round-to-nearest bf16 of what the pieces before it left: 3 x 8 significand bits
+// and bf16 has fp32's exponent range, so nothing is scaled and nothing can overflow that fp32 holds), and a
+// product keeps the six piece products down to 2^-16 of it,
+//      a.b ~ a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1      (dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-23 |a b|),
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the rounding of an fp32 fma chain (2^-24 per step), at
+// 16 / 6 of the fp32 MFMA rate.  A block owns the whole 256 x 256 output of one split of the points.
+//
+// Data path per 16-point chunk: thread t loads column t of the delta tile and of the activation tile (16 dwords
+// each, a row of the tile per wave instruction), splits them and stores the pieces FRAGMENT-READY in LDS --
+// [matrix][32-channel tile][piece][lane (i, hh)][8 bf16 = points 8 hh .. 8 hh + 7 of channel i]: the thread's own
+// 16 bytes per piece and lane half, conflict free -- while the chunk before is multiplied; the registers then take
+// the chunk after next straight away, so a load has a whole chunk to land.  Two LDS buffers of 48 KiB, one
+// counted wait + raw barrier per chunk.  The bias gradient (column sums of delta) is added up by the thread
+// that holds the column anyway.
+// ---------------------------------------------------------------------------
+typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned tn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma_bf16(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tn_bf16x8, a), __builtin_bit_cast(tn_bf16x8, b), c, 0, 0, 0);
+}
+// (low half, high half) = (bf16(x0), bf16(x1)), round to nearest even
+__device__ __forceinline__ unsigned tn_cvt_pk_bf16(float x0, float x1) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+    return r;
+}
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = tn_cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);   // exact
+    p2 = tn_cvt_pk_bf16(r0, r1);
+    r0 = r0 - __uint_as_float(p2 << 16);
+    r1 = r1 - __uint_as_float(p2 & 0xffff0000u);
+    p3 = tn_cvt_pk_bf16(r0, r1);
+}
+constexpr int kX6BufBytes = 2 * 8 * 3 * kFragBytes;   // (delta, acts) x 8 tiles x 3 pieces x 1 KiB
+constexpr int kX6Lds = 2 * kX6BufBytes;
+
+struct X6Frag {
+    f32x4 v;
+    template <int OFF>
+    __device__ __forceinline__ void issue(uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); }
+};
+// at most N of this wave's LDS operations are still outstanding => the three fragments named are valid
+template <int N>
+__device__ __forceinline__ void x6_retire(X6Frag (&f)[3]) {
+    static_assert(N <= 15, "lgkmcnt is a 4-bit field");
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f[0].v), "+v"(f[1].v), "+v"(f[2].v) : "n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char x6_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hh = lane >> 5;
+    const int wr = w >> 1, wc = w & 1;
+    const int split = blockIdx.z;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const long c_begin = (long)split * g.chunks_per_split;
+    long c_end = c_begin + g.chunks_per_split;
+    const long c_total = g.P / kTnRows;
+    if (c_end > c_total) c_end = c_total;
+    const int n_chunks = (int)(c_end - c_begin);          // >= 1 (run_tn_partials sizes the splits so)
+    // descriptors based at this split's first row (32-bit offsets span one split)
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + c_begin * kTnRows * (long)g.lda), 0, 0xfffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + c_begin * kTnRows * (long)g.ldb), 0, 0xfffffffc, 0x00020000);
+    const int voff = tid * 4;
+    const int rowA = g.lda * 4, rowB = g.ldb * 4;
+    float ra[kTnRows], rb[kTnRows];
+    auto load_a = [&](int rc) {   // chunk rc of this split, clamped to its last one (re-read, never used)
+        const int base = (rc < n_chunks ? rc : n_chunks - 1) * kTnRows;
+#pragma unroll
+        for (int p = 0; p < kTnRows; ++p) ra[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcA, voff, (base + p) * rowA, 0));
+    };
+    auto load_b = [&](int rc) {
+        const int base = (rc < n_chunks ? rc : n_chunks - 1) * kTnRows;
+#pragma unroll
+        for (int p = 0; p < kTnRows; ++p) rb[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcB, voff, (base + p) * rowB, 0));
+    };
+    // this thread's slot: tile tid / 32, lane (tid % 32, hh) -> hh-th half of the fragment
+    char* const my_slot = x6_smem + (tid >> 5) * (3 * kFragBytes) + (tid & 31) * 16;
+    auto split_store = [&](int buf, int X, const float (&r)[kTnRows]) {
+        unsigned pw[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(r[2 * j], r[2 * j + 1], pw[0][j], pw[1][j], pw[2][j]);
+        char* dst = my_slot + buf * kX6BufBytes + X * (8 * 3 * kFragBytes);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+                *reinterpret_cast<tn_u32x4*>(dst + q * kFragBytes + h2 * 512) =
+                    tn_u32x4{pw[q][4 * h2], pw[q][4 * h2 + 1], pw[q][4 * h2 + 2], pw[q][4 * h2 + 3]};
+    };
+    const bool do_colsum = g.cpart != nullptr;
+    float csum = 0.0f;
+    auto colsum = [&](float live) {   // live = 1 for a chunk of this split, 0 for the clamped re-read
+        float s0 = (ra[0] + ra[1]) + (ra[2] + ra[3]), s1 = (ra[4] + ra[5]) + (ra[6] + ra[7]);
+        float s2 = (ra[8] + ra[9]) + (ra[10] + ra[11]), s3 = (ra[12] + ra[13]) + (ra[14] + ra[15]);
+        csum += live * ((s0 + s1) + (s2 + s3));
+    };
+    const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)x6_smem;
+    const uint32_t a_base = smem0 + (4 * wr) * (3 * kFragBytes) + lane * 16;
+    const uint32_t b_base = smem0 + (8 + 4 * wc) * (3 * kFragBytes) + lane * 16;
+
+    load_a(0);
+    load_b(0);
+    colsum(1.0f);
+    split_store(0, 0, ra);
+    split_store(0, 1, rb);
+    load_a(1);
+    load_b(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+#pragma unroll 1
+    for (int rc = 0; rc < n_chunks; ++rc) {
+        const int buf = rc & 1;
+        const uint32_t pa = a_base + buf * kX6BufBytes, pb = b_base + buf * kX6BufBytes;
+        X6Frag fa[4][3], fb[4][3];
+        // issue order = consumption order of row 0, then the other delta tiles
+        tn_static_for<3>([&](auto Q) { fa[0][decltype(Q)::value].template issue<decltype(Q)::value * kFragBytes>(pa); });
+        tn_static_for<4>([&](auto Y) {
+            tn_static_for<3>([&](auto Q) {
+                fb[decltype(Y)::value][decltype(Q)::value].template issue<(decltype(Y)::value * 3 + decltype(Q)::value) * kFragBytes>(pb);
+            });
+        });
+        tn_static_for<3>([&](auto X) {
+            tn_static_for<3>([&](auto Q) {
+                fa[decltype(X)::value + 1][decltype(Q)::value].template issue<((decltype(X)::value + 1) * 3 + decltype(Q)::value) * kFragBytes>(pa);
+            });
+        });
+        auto mm2 = [&](int x, int y0, int y1) {   // two tile pairs, interleaved: six piece products each
+#define X6_TERM(QA, QB)                                                   \
+    acc[x][y0] = mfma_bf16(fa[x][QA].v, fb[y0][QB].v, acc[x][y0]);        \
+    acc[x][y1] = mfma_bf16(fa[x][QA].v, fb[y1][QB].v, acc[x][y1]);
+            X6_TERM(0, 0) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(1, 1) X6_TERM(0, 2) X6_TERM(2, 0)
+#undef X6_TERM
+        };
+        // row 0: 24 reads are outstanding; fa[0], fb[0], fb[1] are the oldest nine
+        x6_retire<15>(fa[0]);
+        x6_retire<15>(fb[0]);
+        x6_retire<15>(fb[1]);
+        mm2(0, 0, 1);
+        x6_retire<9>(fb[2]);
+        x6_retire<9>(fb[3]);
+        mm2(0, 2, 3);
+        x6_retire<0>(fa[1]);
+        x6_retire<0>(fa[2]);
+        x6_retire<0>(fa[3]);
+        // rows 1..3 with the next chunk's split + store and the loads of the chunk after it in their shadow
+        const float live = rc + 1 < n_chunks ? 1.0f : 0.0f;
+        mm2(1, 0, 1);
+        colsum(live);   // (unconditional: a branch here would cut the MFMA sequence in two)
+        split_store(buf ^ 1, 0, ra);
+        load_a(rc + 2);
+        mm2(1, 2, 3);
+        mm2(2, 0, 1);
+        split_store(buf ^ 1, 1, rb);
+        load_b(rc + 2);
+        mm2(2, 2, 3);
+        mm2(3, 0, 1);
+        mm2(3, 2, 3);
+        // everyone's pieces of chunk rc + 1 are in LDS; everyone has read chunk rc's
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (do_colsum) g.cpart[(long)split * g.N + tid] = csum;
+    // lane (i, hh), tile (x, y), register r: output (32 (4 wr + x) + d_row(r, hh), 32 (4 wc + y) + i)
+    float* out = g.part + (long)split * g.N * g.K;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(long)(32 * (4 * wr + x) + d_row(r, hh)) * g.K + 32 * (4 * wc + y) + i] = acc[x][y][r];
 }
 
 // out[n*ldo + k] = sum_s part[s][n][k],  n < rows, k < cols  (rows/cols may be smaller than N/K: padding dropped)
@@ -603,6 +793,20 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
         }, &num_cu))
         return e;
     ProfScope prof(s, P, IDN_PROF_DW_GEMM);
+#if IDN_DW_X6
+    if (ntw == 4 && ktw == 4) {
+        static LaunchSetup setup6;
+        if (int e = setup6.get([]() -> int {
+                IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kX6Lds));
+                return IDN_OK;
+            }, &num_cu))
+            return e;
+        hipLaunchKernelGGL(gemm_tn_x6_kernel, grid, block, kX6Lds, s, g);
+        IDN_HIP_CHECK(hipGetLastError());
+        *splits_out = splits;
+        return IDN_OK;
+    }
+#endif
     if (ntw == 4 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, lds, s, g);
     else if (ntw == 4 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), grid, block, lds, s, g);
     else if (ntw == 2 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<2, 4>), grid, block, lds, s, g);
