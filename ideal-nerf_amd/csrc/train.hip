@@ -88,6 +88,8 @@ __device__ __forceinline__ void lds_retire(VA& a, VB& b) {
     if constexpr (NEWER == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v), "+v"(b.v)::"memory");
     else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a.v), "+v"(b.v)::"memory");
 }
+template <int N>
+using ic_ = std::integral_constant<int, N>;
 template <int N, class F>
 __device__ __forceinline__ void tn_static_for(F&& f) {
     if constexpr (N > 0) {
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 // ---------------------------------------------------------------------------
 typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned tn_u32x4 __attribute__((ext_vector_type(4)));
+typedef int tn_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma_bf16(f32x4 a, f32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tn_bf16x8, a), __builtin_bit_cast(tn_bf16x8, b), c, 0, 0, 0);
 }
@@ -379,21 +382,31 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNArgs g) {
     const long c_total = g.P / kTnRows;
     if (c_end > c_total) c_end = c_total;
     const int n_chunks = (int)(c_end - c_begin);          // >= 1 (run_tn_partials sizes the splits so)
-    // descriptors based at this split's first row (32-bit offsets span one split)
-    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + c_begin * kTnRows * (long)g.lda), 0, 0xfffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + c_begin * kTnRows * (long)g.ldb), 0, 0xfffffffc, 0x00020000);
+    // Raw buffer descriptors based at this split's first row (32-bit offsets span one split).  The loads are inline asm
+    // with the destination tied to the register that held the same row of the chunk before ("+v"): as a builtin the
+    // reload got a fresh register and a copy at the loop end -- behind a wait for the load, a chunk early.  vmcnt is
+    // therefore counted by hand: loads are issued in ONE order (delta rows 0..15, activation rows 0..15) everywhere,
+    // so when pair j is split, exactly 30 loads are younger than its second row.
+    auto make_rsrc = [](const float* ptr) {
+        const uint64_t a64 = (uint64_t)(uintptr_t)ptr;
+        return tn_i32x4{(int)(uint32_t)a64, (int)((uint32_t)(a64 >> 32) & 0xffffu), (int)0xfffffffcu, 0x00020000};
+    };
+    const tn_i32x4 rsrcA = make_rsrc(g.A + c_begin * kTnRows * (long)g.lda);
+    const tn_i32x4 rsrcB = make_rsrc(g.B + c_begin * kTnRows * (long)g.ldb);
     const int voff = tid * 4;
     const int rowA = g.lda * 4, rowB = g.ldb * 4;
     float ra[kTnRows], rb[kTnRows];
-    auto load_a = [&](int rc) {   // chunk rc of this split, clamped to its last one (re-read, never used)
-        const int base = (rc < n_chunks ? rc : n_chunks - 1) * kTnRows;
 #pragma unroll
-        for (int p = 0; p < kTnRows; ++p) ra[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcA, voff, (base + p) * rowA, 0));
+    for (int p = 0; p < kTnRows; ++p) ra[p] = rb[p] = 0.f;
+    auto load_row = [&](float& dst, const tn_i32x4& rsrc, int soff) {
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     };
-    auto load_b = [&](int rc) {
+    auto load_chunk = [&](int rc) {   // chunk rc of this split, clamped to its last one (re-read, never used)
         const int base = (rc < n_chunks ? rc : n_chunks - 1) * kTnRows;
 #pragma unroll
-        for (int p = 0; p < kTnRows; ++p) rb[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcB, voff, (base + p) * rowB, 0));
+        for (int p = 0; p < kTnRows; ++p) load_row(ra[p], rsrcA, (base + p) * rowA);
+#pragma unroll
+        for (int p = 0; p < kTnRows; ++p) load_row(rb[p], rsrcB, (base + p) * rowB);
     };
     // this thread's slot: tile tid / 32, lane (tid % 32, hh) -> hh-th half of the fragment
     char* const my_slot = x6_smem + (tid >> 5) * (3 * kFragBytes) + (tid & 31) * 16;
@@ -410,23 +423,23 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNArgs g) {
                     tn_u32x4{pw[q][4 * h2], pw[q][4 * h2 + 1], pw[q][4 * h2 + 2], pw[q][4 * h2 + 3]};
     };
     const bool do_colsum = g.cpart != nullptr;
-    float csum = 0.0f;
-    auto colsum = [&](float live) {   // live = 1 for a chunk of this split, 0 for the clamped re-read
+    float csum = 0.0f, csum1 = 0.0f;
+    auto colsum = [&]() {   // chunk 0 (the loop adds the others as it splits them)
         float s0 = (ra[0] + ra[1]) + (ra[2] + ra[3]), s1 = (ra[4] + ra[5]) + (ra[6] + ra[7]);
         float s2 = (ra[8] + ra[9]) + (ra[10] + ra[11]), s3 = (ra[12] + ra[13]) + (ra[14] + ra[15]);
-        csum += live * ((s0 + s1) + (s2 + s3));
+        csum += (s0 + s1) + (s2 + s3);
     };
     const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)x6_smem;
     const uint32_t a_base = smem0 + (4 * wr) * (3 * kFragBytes) + lane * 16;
     const uint32_t b_base = smem0 + (8 + 4 * wc) * (3 * kFragBytes) + lane * 16;
 
-    load_a(0);
-    load_b(0);
-    colsum(1.0f);
+    load_chunk(0);
+#pragma unroll
+    for (int p = 0; p < kTnRows; ++p) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[p]), "+v"(rb[p])::"memory");
+    colsum();
     split_store(0, 0, ra);
     split_store(0, 1, rb);
-    load_a(1);
-    load_b(1);
+    load_chunk(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -466,25 +479,74 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNArgs g) {
         x6_retire<0>(fa[1]);
         x6_retire<0>(fa[2]);
         x6_retire<0>(fa[3]);
-        // rows 1..3 with the next chunk's split + store and the loads of the chunk after it in their shadow
-        const float live = rc + 1 < n_chunks ? 1.0f : 0.0f;
-        mm2(1, 0, 1);
-        colsum(live);   // (unconditional: a branch here would cut the MFMA sequence in two)
-        split_store(buf ^ 1, 0, ra);
-        load_a(rc + 2);
-        mm2(1, 2, 3);
-        mm2(2, 0, 1);
-        split_store(buf ^ 1, 1, rb);
-        load_b(rc + 2);
-        mm2(2, 2, 3);
-        mm2(3, 0, 1);
-        mm2(3, 2, 3);
+        // Rows 1..3: 72 MFMAs, each followed by one SLICE of the side work (the next chunk's split + store, the reloads
+        // with the chunk after it) and a scheduling fence: at most ~6 vector instructions, two loads or one store behind
+        // an MFMA that occupies the pipe for 32 cycles.  (Left alone, hipcc issues 40 MFMAs back to back and then 50
+        // vector and memory instructions in a row, during which the matrix pipe runs dry: 57 % busy.)
+        const unsigned live_mask = rc + 1 < n_chunks ? 0xffffffffu : 0u;   // the clamped re-read of the last chunk does not count
+        const int nbase = (rc + 2 < n_chunks ? rc + 2 : n_chunks - 1) * kTnRows;   // chunk rc + 2, clamped (re-read, never used)
+        char* const dst = my_slot + (buf ^ 1) * kX6BufBytes;
+        unsigned pw[2][3][8];
+        float t0 = 0.f, t1 = 0.f;
+        auto slice = [&](auto X_, auto S_) {
+            constexpr int X = decltype(X_)::value, sl = decltype(S_)::value;
+            float (&r)[kTnRows] = *(X ? &rb : &ra);
+            auto store = [&](auto Q_, auto H_) {
+                constexpr int q = decltype(Q_)::value, h2 = decltype(H_)::value;
+                *reinterpret_cast<tn_u32x4*>(dst + X * (8 * 3 * kFragBytes) + q * kFragBytes + h2 * 512) =
+                    tn_u32x4{pw[X][q][4 * h2], pw[X][q][4 * h2 + 1], pw[X][q][4 * h2 + 2], pw[X][q][4 * h2 + 3]};
+            };
+            if constexpr (sl < 24) {
+                constexpr int j = sl / 3, ph = sl % 3;
+                if constexpr (ph == 0) {
+                    // rows 2 j, 2 j + 1 of the chunk being split have landed: 30 younger loads may still be in flight
+                    asm volatile("s_waitcnt vmcnt(30)" : "+v"(r[2 * j]), "+v"(r[2 * j + 1])::"memory");
+                    const unsigned p1 = tn_cvt_pk_bf16(r[2 * j], r[2 * j + 1]);
+                    pw[X][0][j] = p1;
+                    t0 = r[2 * j] - __uint_as_float(p1 << 16);
+                    t1 = r[2 * j + 1] - __uint_as_float(p1 & 0xffff0000u);
+                    if constexpr (X == 0) {   // (masked, not multiplied: packed-fp32 forms would tie the reload registers to aligned pairs)
+                        csum += __uint_as_float(__float_as_uint(r[2 * j]) & live_mask);
+                        csum1 += __uint_as_float(__float_as_uint(r[2 * j + 1]) & live_mask);
+                        // pinned here: hipcc otherwise keeps the 16 values for one batch of adds at the end, i.e. copies every
+                        // row register before its reload (and copies in-flight registers back at the loop end)
+                        asm volatile("" : "+v"(csum), "+v"(csum1));
+                    }
+                } else if constexpr (ph == 1) {
+                    const unsigned p2 = tn_cvt_pk_bf16(t0, t1);
+                    pw[X][1][j] = p2;
+                    t0 = t0 - __uint_as_float(p2 << 16);
+                    t1 = t1 - __uint_as_float(p2 & 0xffff0000u);
+                    pw[X][2][j] = tn_cvt_pk_bf16(t0, t1);
+                } else {
+                    load_row(r[2 * j], X ? rsrcB : rsrcA, (nbase + 2 * j) * (X ? rowB : rowA));
+                    load_row(r[2 * j + 1], X ? rsrcB : rsrcA, (nbase + 2 * j + 1) * (X ? rowB : rowA));
+                    if constexpr (j >= 3 && j < 6) store(ic_<j - 3>{}, ic_<0>{});
+                    if constexpr (j == 7) store(ic_<0>{}, ic_<1>{});
+                }
+            } else if constexpr (sl == 24) {
+                store(ic_<1>{}, ic_<1>{});
+            } else if constexpr (sl == 25) {
+                store(ic_<2>{}, ic_<1>{});
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        tn_static_for<72>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            constexpr int x = 1 + k / 24, kk = k % 24, y = 2 * (kk / 12) + (kk % 2), t = (kk % 12) / 2;
+            constexpr int qa = t == 2 || t == 3 ? 1 : (t == 5 ? 2 : 0);   // a1 b1, a1 b2, a2 b1, a2 b2, a1 b3, a3 b1
+            constexpr int qb = t == 1 || t == 3 ? 1 : (t == 4 ? 2 : 0);
+            acc[x][y] = mfma_bf16(fa[x][qa].v, fb[y][qb].v, acc[x][y]);
+            if constexpr (k < 36) slice(ic_<0>{}, ic_<k>{});
+            else slice(ic_<1>{}, ic_<k - 36>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
         // everyone's pieces of chunk rc + 1 are in LDS; everyone has read chunk rc's
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    if (do_colsum) g.cpart[(long)split * g.N + tid] = csum;
+    if (do_colsum) g.cpart[(long)split * g.N + tid] = csum + csum1;
     // lane (i, hh), tile (x, y), register r: output (32 (4 wr + x) + d_row(r, hh), 32 (4 wc + y) + i)
     float* out = g.part + (long)split * g.N * g.K;
 #pragma unroll
@@ -792,9 +854,9 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
             return IDN_OK;
         }, &num_cu))
         return e;
-    ProfScope prof(s, P, IDN_PROF_DW_GEMM);
 #if IDN_DW_X6
     if (ntw == 4 && ktw == 4) {
+        ProfScope prof(s, P, IDN_PROF_DW_GEMM_X6);
         static LaunchSetup setup6;
         if (int e = setup6.get([]() -> int {
                 IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kX6Lds));
@@ -807,6 +869,7 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
         return IDN_OK;
     }
 #endif
+    ProfScope prof(s, P, IDN_PROF_DW_GEMM);
     if (ntw == 4 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, lds, s, g);
     else if (ntw == 4 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), grid, block, lds, s, g);
     else if (ntw == 2 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<2, 4>), grid, block, lds, s, g);

@@ -283,6 +283,19 @@ def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(ok)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
+    # the same for inline-asm buffer loads into registers, retired by counted vmcnt waits (the bf16 dW GEMM reloads
+    # its row registers in place): a copy of a register whose load is still in flight is flagged, a copy behind the
+    # counted wait that covers it is not
+    vm = tmp_path / "vm.s"
+    vm.write_text("_Z12fake_kernel3v:\n.LBB0_1:\n\t;;#ASMSTART\n\tbuffer_load_dword v5, v1, s[8:11], s24 offen\n\t;;#ASMEND\n"
+                  "\t;;#ASMSTART\n\tbuffer_load_dword v6, v1, s[8:11], s25 offen\n\t;;#ASMEND\n"
+                  "\t;;#ASMSTART\n\ts_waitcnt vmcnt(1)\n\t;;#ASMEND\n"
+                  "\tv_mov_b32_e32 v7, v6\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\ts_cbranch_scc0 .LBB0_1\n\ts_endpgm\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(vm)], capture_output=True, text=True)
+    assert r.returncode == 1 and "asm load at line" in r.stdout, r.stdout
+    vm.write_text(vm.read_text().replace("v_mov_b32_e32 v7, v6", "v_mov_b32_e32 v7, v5"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(vm)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
 
 
 def test_config_files_parse_like_the_reference(idn):

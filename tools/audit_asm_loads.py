@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Audit hipcc output for the in-flight window of inline-asm LDS reads.
+"""Audit hipcc output for the in-flight window of inline-asm LDS reads and inline-asm buffer loads.
 
 An `asm volatile("ds_read_b128 %0, ...")` destination counts, for the compiler, as written at
 the end of the asm statement -- but the data lands ~100+ cycles later.  Any compiler-generated
 instruction that reads or writes those registers before the asm `s_waitcnt lgkmcnt(N)` that
 retires them sees/destroys garbage (cdna_hip_programming.md 5.7).  This script walks each
 kernel in a .s file along every control-flow path (branches and loops followed), tracks the
-destination ranges of asm ds_reads and reports every non-asm instruction that touches a range
-while it is in flight.
+destination ranges of asm ds_reads (retired by asm `s_waitcnt lgkmcnt`) and of asm buffer / global
+loads into registers (retired by asm `s_waitcnt vmcnt`) and reports every non-asm instruction that
+touches a range while it is in flight.
 
 Second check, same walk: an inline-asm VALU instruction that reads a VGPR an MFMA wrote a few
 instructions earlier.  The hazard recogniser inserts the wait states an MFMA result needs before
@@ -70,12 +71,15 @@ def audit_mfma_to_asm_valu(insts, name):
 
 def audit_inflight(insts, labels, name):
     """First check, along every control-flow path (loops included): state = the ordered destinations of the asm
-    ds_reads still in flight.  Each (instruction, state) pair is explored once; the states a loop produces
-    repeat after an iteration, so the walk terminates (capped all the same)."""
+    ds_reads (retired by lgkmcnt) and of the asm buffer / global loads (retired by vmcnt) still in flight.  Each
+    (instruction, state) pair is explored once; the states a loop produces repeat after an iteration, so the walk
+    terminates (capped all the same)."""
     bad, reported = 0, set()
     seen = set()
-    work = [(0, ())]
+    work = [(0, ((), ()))]
     steps = 0
+    CAP = (32, 64)   # more asm loads than this in flight on a path = never retired (vmcnt is a 6-bit counter)
+    KIND = ("ds_read", "load")
     while work and steps < 2_000_000:
         idx, state = work.pop()
         while idx < len(insts):
@@ -85,25 +89,36 @@ def audit_inflight(insts, labels, name):
             seen.add(key)
             steps += 1
             no, code, in_asm = insts[idx]
+            lds, vm = state
             if in_asm:
-                if code.startswith('ds_read'):
-                    state = state + ((frozenset(regs(code.split()[1].rstrip(','))), no),)
-                    if len(state) > 32:   # a path that keeps issuing without ever retiring (the walk would not terminate)
+                q = 0 if code.startswith('ds_read') else (1 if code.startswith(('buffer_load', 'global_load')) and ' lds' not in code else -1)
+                if q >= 0:
+                    entry = (frozenset(regs(code.split()[1].rstrip(','))), no)
+                    lds, vm = (lds + (entry,), vm) if q == 0 else (lds, vm + (entry,))
+                    if len((lds, vm)[q]) > CAP[q]:
                         if ('unbounded', no) not in reported:
                             reported.add(('unbounded', no))
                             bad += 1
-                            print(f"  {name}: line {no}: more than 32 asm ds_reads in flight on some path (never retired)")
+                            print(f"  {name}: line {no}: more than {CAP[q]} asm {KIND[q]}s in flight on some path (never retired)")
                         break
                 elif code.startswith('s_waitcnt'):
                     m = re.search(r'lgkmcnt\((\d+)\)', code)
                     if m:
                         keep = int(m.group(1))
-                        state = state[len(state) - keep:] if keep else ()
+                        lds = lds[len(lds) - keep:] if keep else ()
+                    m = re.search(r'vmcnt\((\d+)\)', code)
+                    if m:
+                        keep = int(m.group(1))
+                        vm = vm[max(0, len(vm) - keep):] if keep else ()
+                state = (lds, vm)
                 idx += 1
                 continue
             if code.startswith('s_waitcnt'):
                 if 'lgkmcnt(0)' in code:
-                    state = ()   # the compiler's own full LDS wait retires everything
+                    lds = ()   # the compiler's own full LDS wait retires everything
+                if 'vmcnt(0)' in code:
+                    vm = ()
+                state = (lds, vm)
                 idx += 1
                 continue
             if code.startswith('s_endpgm'):
@@ -118,13 +133,14 @@ def audit_inflight(insts, labels, name):
                 continue
             if not code.startswith('s_barrier'):
                 touched = regs(code)
-                for rs, at in state:
-                    hit = touched & rs
-                    if hit and (no, at) not in reported:
-                        reported.add((no, at))
-                        bad += 1
-                        if bad <= 12:
-                            print(f"  {name}: line {no}: `{code}` touches {sorted(hit)[:4]} (asm ds_read at line {at} still in flight)")
+                for q, queue in enumerate((lds, vm)):
+                    for rs, at in queue:
+                        hit = touched & rs
+                        if hit and (no, at) not in reported:
+                            reported.add((no, at))
+                            bad += 1
+                            if bad <= 12:
+                                print(f"  {name}: line {no}: `{code}` touches {sorted(hit)[:4]} (asm {KIND[q]} at line {at} still in flight)")
             idx += 1
     return bad
 
