@@ -74,6 +74,8 @@ PROTOTYPES = {
     "idealnerf_pass_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "idealnerf_pass_bwd": (C.c_int, [C.POINTER(FaceNerfParams), C.POINTER(FaceNerfGrads), fp, fp, fp, fp, fp, fp, fp,
                                      fp, C.c_int64, C.c_int, fp, fp, fp, fp, fp, fp, fp, C.c_size_t, fp]),
+    "idealnerf_dw_gemm_workspace_bytes": (C.c_size_t, []),
+    "idealnerf_dw_gemm": (C.c_int, [fp, C.c_int, fp, C.c_int, C.c_int64, fp, fp, C.c_int, fp, C.c_size_t, fp]),
     "idealnerf_profile_begin": (None, []),
     "idealnerf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "idealnerf_profile_end_kinds": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

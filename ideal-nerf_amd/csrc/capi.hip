@@ -267,6 +267,14 @@ int idealnerf_pass_bwd(const idn_facenerf_params* p, const idn_facenerf_grads* g
                            (hipStream_t)stream);
 }
 
+size_t idealnerf_dw_gemm_workspace_bytes(void) { return dw_gemm_workspace_bytes(); }
+
+int idealnerf_dw_gemm(const float* delta, int ld_delta, const float* acts, int ld_acts, int64_t rows, float* dW, float* db,
+                      int pipe, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!delta || !acts || !dW) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_dw_gemm(delta, ld_delta, acts, ld_acts, rows, dW, db, pipe, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 void idealnerf_profile_begin(void) {
     g_prof_n = 0;
     g_prof_on = true;

@@ -239,6 +239,9 @@ int launch_pack_f32_bwd(const idn_facenerf_params& p, float* packed_bwd, hipStre
 int launch_delta_chain(const float* packed_bwd, const float* acts, int64_t p_pad, const float* d_rgb, float* dv0,
                        float* dv2, float* dv1, float* const da[8], hipStream_t s);
 size_t bwd_workspace_bytes(int64_t n_points);
+size_t dw_gemm_workspace_bytes();
+int launch_dw_gemm(const float* delta, int ld_delta, const float* acts, int ld_acts, int64_t rows, float* dW, float* db, int pipe,
+                   void* ws, size_t ws_bytes, hipStream_t s);
 int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, const float* aud, const float* expr,
                     const float* latent, const float* acts, const float* raw, const float* z, const float* rays,
                     const float* bc, int64_t n_rays, int S, const float* g_rgb, const float* g_fg, const float* g_lw,

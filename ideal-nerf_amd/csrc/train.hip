@@ -822,8 +822,9 @@ size_t bwd_workspace_bytes(int64_t n_points) {
 }
 
 // part[split][N][K] = A[:, :N]^T . B[:, :K] over point splits; returns the split count
+enum { kPipeX6 = 0, kPipeF32 = 1 };   // which matrix pipe a 256 x 256 GEMM runs on (the other shapes: fp32)
 static int run_tn_partials(const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part,
-                           int* splits_out, hipStream_t s, float* cpart = nullptr) {
+                           int* splits_out, hipStream_t s, float* cpart = nullptr, int pipe = IDN_DW_X6 ? kPipeX6 : kPipeF32) {
     int ntw, ktw;
     if (N == 256 && K == 256) { ntw = 4; ktw = 4; }
     else if (N == 256 && K == 64) { ntw = 4; ktw = 1; }
@@ -854,8 +855,7 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
             return IDN_OK;
         }, &num_cu))
         return e;
-#if IDN_DW_X6
-    if (ntw == 4 && ktw == 4) {
+    if (ntw == 4 && ktw == 4 && pipe == kPipeX6) {
         ProfScope prof(s, P, IDN_PROF_DW_GEMM_X6);
         static LaunchSetup setup6;
         if (int e = setup6.get([]() -> int {
@@ -868,7 +868,6 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
         *splits_out = splits;
         return IDN_OK;
     }
-#endif
     ProfScope prof(s, P, IDN_PROF_DW_GEMM);
     if (ntw == 4 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, lds, s, g);
     else if (ntw == 4 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), grid, block, lds, s, g);
@@ -968,10 +967,10 @@ struct ReduceQueue {
 };
 // GEMM into a fresh slab of the pool; *part_out / *cpart_out are where its partial blocks went
 static int run_tn_q(ReduceQueue& q, const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, int* splits,
-                    const float** part_out, const float** cpart_out, bool colsum, hipStream_t s) {
+                    const float** part_out, const float** cpart_out, bool colsum, hipStream_t s, int pipe) {
     float* part = q.part_next;
     float* cpart = colsum ? q.cpart_next : nullptr;
-    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, splits, s, cpart)) return e;
+    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, splits, s, cpart, pipe)) return e;
     q.part_next += (size_t)(*splits) * N * K;
     if (colsum) q.cpart_next += (size_t)(*splits) * N;
     *part_out = part;
@@ -980,13 +979,30 @@ static int run_tn_q(ReduceQueue& q, const float* A, int lda, int N, const float*
 }
 // out = A^T B (rows x cols of it); db (optional, `db_cols` entries) = column sums of A, from the same pass over A
 static int run_tn(ReduceQueue& q, const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* out,
-                  int ldo, int rows, int cols, hipStream_t s, float* db = nullptr, int db_cols = 0) {
+                  int ldo, int rows, int cols, hipStream_t s, float* db = nullptr, int db_cols = 0,
+                  int pipe = IDN_DW_X6 ? kPipeX6 : kPipeF32) {
     int splits = 0;
     const float *part, *cpart;
-    if (int e = run_tn_q(q, A, lda, N, B, ldb, K, P, &splits, &part, &cpart, db != nullptr, s)) return e;
+    if (int e = run_tn_q(q, A, lda, N, B, ldb, K, P, &splits, &part, &cpart, db != nullptr, s, pipe)) return e;
     if (db)
         if (int e = q.add(cpart, splits, 1, N, 0, 0, db, N, 1, db_cols)) return e;
     return q.add(part, splits, N, K, 0, 0, out, ldo, rows, cols);
+}
+
+// One 256 x 256 dW GEMM in isolation (idealnerf_dw_gemm: the arithmetic of the bf16-piece GEMM against the fp32 pipe
+// and fp64, on inputs a training step does not produce).
+size_t dw_gemm_workspace_bytes() { return al256((size_t)kMaxSplits * 65536 * 4) + al256((size_t)kColsumBlocks * 256 * 4); }
+int launch_dw_gemm(const float* delta, int ld_delta, const float* acts, int ld_acts, int64_t rows, float* dW, float* db, int pipe,
+                   void* ws, size_t ws_bytes, hipStream_t s) {
+    if (rows <= 0 || rows % 128) return fail(IDN_EINVAL, "dw_gemm: rows %lld is not a positive multiple of 128", (long long)rows);
+    if (ld_delta < 256 || ld_acts < 256) return fail(IDN_EINVAL, "dw_gemm: row pitch < 256");
+    if (pipe != kPipeX6 && pipe != kPipeF32) return fail(IDN_EINVAL, "dw_gemm: pipe %d", pipe);
+    if (!ws || ws_bytes < dw_gemm_workspace_bytes()) return fail(IDN_EWORKSPACE, "dw_gemm workspace %zu < %zu", ws_bytes, dw_gemm_workspace_bytes());
+    float* part = reinterpret_cast<float*>(ws);
+    float* cpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + al256((size_t)kMaxSplits * 65536 * 4));
+    ReduceQueue q(part, cpart);
+    if (int e = run_tn(q, delta, ld_delta, 256, acts, ld_acts, 256, rows, dW, 256, 256, 256, s, db, db ? 256 : 0, pipe)) return e;
+    return q.flush(s);
 }
 
 int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, const float* aud, const float* expr,

@@ -335,6 +335,24 @@ def invert_cdf(cdf, bins, u):
     return zs, inds
 
 
+def dw_gemm(delta, acts, pipe=0, with_bias=True):
+    """Test aid: one 256 x 256 weight-gradient product of the training step in isolation (idealnerf_dw_gemm):
+    delta [rows, >= 256], acts [rows, >= 256] (row pitch = their width) -> dW [256, 256] = delta[:, :256]^T acts[:, :256]
+    and db [256] = column sums of delta.  pipe 0: six bf16 piece products (what the step runs), 1: fp32 MFMA."""
+    lib = _lib.load()
+    _shape(delta, "delta", None, None)
+    rows = delta.shape[0]
+    _shape(acts, "acts", rows, None)
+    with _Launch(delta, acts) as L:
+        dW = torch.empty((256, 256), dtype=torch.float32, device=delta.device)
+        db = torch.empty(256, dtype=torch.float32, device=delta.device) if with_bias else None
+        nbytes = lib.idealnerf_dw_gemm_workspace_bytes()
+        ws = _workspace(nbytes, delta.device, L.stream)
+        check(lib.idealnerf_dw_gemm(_ptr(delta, "delta"), delta.shape[1], _ptr(acts, "acts"), acts.shape[1], rows, dW.data_ptr(),
+                                    None if db is None else db.data_ptr(), int(pipe), ws.data_ptr(), ws.numel(), L.stream))
+    return dW, db
+
+
 _workspaces: Dict[tuple, torch.Tensor] = {}
 
 

@@ -295,6 +295,19 @@ int idealnerf_pass_bwd(const idn_facenerf_params* p, const idn_facenerf_grads* g
                        float* d_latent, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Test aid (no reference counterpart): one 256 x 256 weight-gradient product of the training step in isolation,
+ *   dW[256][256] = delta[rows, :256]^T . acts[rows, :256],   db[256] = column sums of delta (may be NULL),
+ * rows a positive multiple of 128, row pitches >= 256 floats.  pipe = IDN_DW_PIPE_BF16X6: as idealnerf_pass_bwd computes
+ * the 256-wide layers (each fp32 operand as the exact sum of three bf16 pieces, six piece products per product on the bf16
+ * matrix pipe, fp32 accumulate); IDN_DW_PIPE_F32: the same product on the fp32 matrix pipe.  tests/ compares both with fp64.
+ */
+#define IDN_DW_PIPE_BF16X6 0
+#define IDN_DW_PIPE_F32 1
+size_t idealnerf_dw_gemm_workspace_bytes(void);
+int idealnerf_dw_gemm(const float* delta, int ld_delta, const float* acts, int ld_acts, int64_t rows, float* dW, float* db,
+                      int pipe, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Frame tail.  to8b = `(255 * np.clip(x, 0, 1)).astype(np.uint8)` (NeRFs/HeadNeRF/helper.py:154) on
  * the device: rgb [n_pixels,3] fp32 -> out [n_pixels,3] u8, bit-identical to numpy for finite input;
  * swap_rb != 0 writes the channels in reverse order (the cv2.cvtColor the reference leaves

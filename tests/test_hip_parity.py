@@ -880,6 +880,49 @@ def test_backward_kernels_vs_fp64_on_saved_activations(idn, dev):
         assert rel_err(d_aud, d_cond[:64]) < 5e-6 and rel_err(d_lat, d_cond[64 + 79:]) < 5e-6
 
 
+def test_dw_gemm_bf16_pieces_match_the_fp32_pipe_against_fp64(idn, dev):
+    """The 256 x 256 weight-gradient GEMM of the training step runs on the bf16 matrix pipe: every fp32 operand as the
+    exact sum of three bf16 pieces, six piece products per product, fp32 accumulate.  Its result must be fp32-grade:
+    compared with an fp64 product of the same inputs it may not be further off than the fp32-MFMA kernel by more than a
+    small factor, on inputs a training step does not produce -- magnitudes over 24 octaves (pieces that underflow each
+    other), heavy cancellation, post-ReLU zeros, one split with a single 16-row chunk, row pitches wider than 256."""
+    rs = np.random.RandomState(11)
+    worst = 0.0
+    for rows, pitch_d, pitch_a, kind in ((128, 256, 256, "normal"), (4096, 256, 320, "wide"), (20480, 384, 256, "wide"),
+                                         (12800, 256, 256, "cancel"), (6400, 256, 256, "relu")):
+        d = rs.standard_normal((rows, pitch_d)).astype(np.float32)
+        a = rs.standard_normal((rows, pitch_a)).astype(np.float32)
+        if kind == "wide":      # log-uniform magnitudes, 2^-12 .. 2^12, per element
+            d *= np.exp2(rs.uniform(-12, 12, d.shape)).astype(np.float32)
+            a *= np.exp2(rs.uniform(-12, 12, a.shape)).astype(np.float32)
+        elif kind == "cancel":  # every column's sum cancels to ~1e-4 of its terms
+            d[1::2] = -d[0::2] * (1 + 1e-4 * rs.standard_normal(d[0::2].shape).astype(np.float32))
+            a[1::2] = a[0::2]
+        elif kind == "relu":
+            a = np.maximum(a, 0)
+            d *= (rs.uniform(size=d.shape) < 0.1)   # sparse deltas
+        dt, at = T(d).to(dev), T(a).to(dev)
+        ref = dt[:, :256].double().t() @ at[:, :256].double()
+        scale = dt[:, :256].double().abs().t() @ at[:, :256].double().abs()   # sum |a||b| per output: the error unit
+        ref_b = dt[:, :256].double().sum(0)
+        err = {}
+        for pipe in (0, 1):
+            dW, db = idn.ops.dw_gemm(dt, at, pipe)
+            assert torch.isfinite(dW).all()
+            err[pipe] = float(((dW.double() - ref).abs() / scale).max())
+            eb = float((db.double() - ref_b).abs().max() / dt[:, :256].double().abs().sum(0).max())
+            assert eb < 3e-7, (kind, rows, pipe, eb)
+        print(f"\n  dW GEMM {kind:6s} rows {rows:6d}: max |err| / sum|a||b|: bf16 pieces {err[0]:.2e}, fp32 pipe {err[1]:.2e}")
+        assert err[0] < 2e-7 and err[0] < 4 * err[1] + 3e-8, (kind, rows, err)
+        worst = max(worst, err[0])
+    # bit-reproducible (no atomics, fixed split and reduction order)
+    dW1, _ = idn.ops.dw_gemm(dt, at, 0)
+    dW2, _ = idn.ops.dw_gemm(dt, at, 0)
+    assert torch.equal(dW1, dW2)
+    with pytest.raises(RuntimeError):
+        idn.ops.dw_gemm(dt[:100].contiguous(), at[:100].contiguous(), 0)   # rows not a multiple of 128
+
+
 # --------------------------------------------------------------------------- bf16x3 arithmetic mode
 BF16X3 = 1  # IDN_PREC_BF16X3
 
