@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDN_LIB") or os.path.join(HERE, "libidealnerf.so")
 
-IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16, IDN_PREC_FP16X3 = 0, 1, 2, 3
+IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16, IDN_PREC_FP16X3, IDN_PREC_BF16X6 = 0, 1, 2, 3, 4
 RAY_FLOATS = 11
 PROF_KINDS = ("mlp_fwd", "mlp_fwd_save", "delta_chain", "dw_gemm", "dw_gemm_x6")   # IDN_PROF_* of include/idealnerf.h
 

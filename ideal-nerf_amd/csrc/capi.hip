@@ -16,9 +16,10 @@ int fail(int code, const char* fmt, ...) {
 }
 
 static int check_precision(int precision) {
-    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3 || precision == IDN_PREC_BF16 || precision == IDN_PREC_FP16X3)
+    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3 || precision == IDN_PREC_BF16 || precision == IDN_PREC_FP16X3 ||
+        precision == IDN_PREC_BF16X6)
         return IDN_OK;
-    return fail(IDN_EUNSUPPORTED, "precision %d is unknown (IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16, IDN_PREC_FP16X3)", precision);
+    return fail(IDN_EUNSUPPORTED, "precision %d is unknown (IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16, IDN_PREC_FP16X3, IDN_PREC_BF16X6)", precision);
 }
 static int check_precision_f32(int precision) {
     if (precision == IDN_PREC_F32) return IDN_OK;
@@ -36,6 +37,8 @@ int launch_mlp(int precision, const float* packed, const float* folded, const fl
         return launch_mlp_bf16(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
     if (precision == IDN_PREC_FP16X3)
         return launch_mlp_fp16x3(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
+    if (precision == IDN_PREC_BF16X6)
+        return launch_mlp_bf16x6(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
     return launch_mlp_f32(packed, folded, x, rays, z, pts, dirs, n_points, n_samples, raw, s);
 }
 
@@ -90,6 +93,7 @@ size_t idealnerf_packed_weight_floats(int precision) {
     // 4 bytes per weight (fp32, or bf16 hi + bf16 lo); 2 for the plain-bf16 stream
     if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3 || precision == IDN_PREC_FP16X3) return (size_t)kStreamFrags * kFragFloats;
     if (precision == IDN_PREC_BF16) return (size_t)kPlainStreamFrags * kFragFloats;
+    if (precision == IDN_PREC_BF16X6) return (size_t)kX6StreamFrags * kFragFloats;   // three bf16 pieces (+ a zero fragment) per weight
     return 0;
 }
 size_t idealnerf_folded_bias_floats(void) { return kBiasFloats; }
@@ -101,6 +105,7 @@ int idealnerf_pack_weights(const idn_facenerf_params* p, int precision, float* p
     if (precision == IDN_PREC_BF16X3) return launch_pack_bf16x3(*p, packed, (hipStream_t)stream);
     if (precision == IDN_PREC_FP16X3) return launch_pack_bf16x3(*p, packed, (hipStream_t)stream, 1);
     if (precision == IDN_PREC_BF16) return launch_pack_bf16(*p, packed, (hipStream_t)stream);
+    if (precision == IDN_PREC_BF16X6) return launch_pack_bf16x6(*p, packed, (hipStream_t)stream);
     return launch_pack_f32(*p, packed, (hipStream_t)stream);
 }
 

@@ -71,6 +71,12 @@ constexpr int kPlainNumSlices =
 constexpr int kPlainStreamFrags = kPlainNumSlices * kSliceFrags;                   // 1152
 static_assert(kPlainUsedFrags == 1122 && kPlainUsedFrags % 2 == 0, "plain stream table changed");
 
+// Six-piece bf16 stream (IDN_PREC_BF16X6): per (n-tile, 16-channel k-step) a quad of fragments (p1, p2, p3, zero) --
+// the three bf16 pieces of each weight -- i.e. twice the fragments of the streams above, layer by layer.
+constexpr int kX6UsedFrags = 2 * kUsedFrags;       // 4488
+constexpr int kX6NumSlices = 2 * kNumSlices;       // 72
+constexpr int kX6StreamFrags = 2 * kStreamFrags;   // 4608
+
 // Folded bias block: one float per output channel, natural channel order
 // (accumulator register 4q+j of tile t, lane half h <-> channel 32 t + 8 q + 4 h + j).
 constexpr int bias_off(int l) {
@@ -173,6 +179,9 @@ struct ProfScope {
 // ---------------------------------------------------------------------------
 int launch_pack_f32(const idn_facenerf_params& p, float* packed, hipStream_t s);
 int launch_pack_bf16x3(const idn_facenerf_params& p, float* packed, hipStream_t s, int fmt = 0);  // fmt 1: fp16 halves
+int launch_pack_bf16x6(const idn_facenerf_params& p, float* packed, hipStream_t s);
+int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
+                      const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
 int launch_pack_bf16(const idn_facenerf_params& p, float* packed, hipStream_t s);
 int launch_mlp_bf16(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
                     const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);

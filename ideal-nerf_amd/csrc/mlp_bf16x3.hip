@@ -178,26 +178,6 @@ __device__ __forceinline__ void run_layer_bf(BTile* out, BTile* deferred, f32x16
     fr.pref1 = a1;
 }
 
-// This lane's input features: calls use(fpt, fdir) with two providers, fpt(ic<K0>) / fdir(ic<K0>) =
-// feature K0 + 4h of gamma_10(point) / gamma_4(view direction) (zero beyond 63 / 27).
-template <int MODE, class Use>
-__device__ __forceinline__ void input_features(const MlpArgs& a, long Pc, int h, const PeLane& pln, const PointIn& in,
-                                               Use&& use) {
-    if constexpr (MODE == kModeX) {
-        const float* xr = a.x + Pc * (IDN_PTS_CH + IDN_VIEWS_CH) + 4 * h;
-        use([&](auto K) { constexpr int k = decltype(K)::value; return (k + 4 * h < IDN_PTS_CH) ? xr[k] : 0.0f; },
-            [&](auto K) { constexpr int k = decltype(K)::value; return (k + 4 * h < IDN_VIEWS_CH) ? xr[IDN_PTS_CH + k] : 0.0f; });
-    } else {
-        float p[3], v[3];
-        point_of<MODE>(in, p, v);
-        PeAxes axp, axd;
-        axp.init(p, h);
-        axd.init(v, h);
-        use([&](auto K) { return pe_slot<decltype(K)::value, 10>(axp, pln); },
-            [&](auto K) { return pe_slot<decltype(K)::value, 4>(axd, pln); });
-    }
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void X3_KERNEL(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

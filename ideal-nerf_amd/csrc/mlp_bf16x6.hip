@@ -1,0 +1,297 @@
+// Fused positional-encoding + FaceNeRF MLP forward on the bf16 matrix pipe at fp32-grade accuracy (gfx950):
+// every fp32 operand -- weight or activation -- is the exact sum of three bf16 pieces
+//      x = p1 + p2 + p3,   p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2)      (round to nearest),
+// 3 x 8 significand bits in fp32's exponent range (nothing is scaled, nothing fp32 holds overflows), and a
+// product keeps the six piece products down to 2^-16 of it,
+//      a.b ~ a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1        (dropped: <= 2^-23 |a b|),
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the rounding of an fp32 fma chain at 16 / 6 of the fp32 MFMA
+// rate.  (bf16x3 keeps two pieces per operand and three products: 1e-5; the third piece is what makes this one
+// fp32-grade.  The training step's 256 x 256 weight-gradient GEMMs use the same arithmetic, train.hip.)
+//
+// Same computation, stream machinery and tile-major layer order as the other MLP kernels.  What differs is where a
+// layer's data lives: the INPUT of a layer is held as pieces (8 tiles x 3 pieces x 2 k-steps x 4 registers = 192
+// registers per wave of 32 points), its OUTPUT as the fp32 accumulator tiles themselves (8 x 16 = 128 registers,
+// like the fp32 kernel); at the end of a layer the accumulators are ReLU'd and split into the piece registers,
+// which the finished layer no longer needs.  (Input and output both as pieces -- the bf16x3 kernel's two ping-pong
+// sets -- would be 384 registers before accumulators and encodings.)
+//
+// Weight stream: per (n-tile, 16-channel k-step) a QUAD of fragments (p1, p2, p3, zero): twice the fragments of the
+// bf16x3 stream, so every layer starts where it does there modulo the ring, and slices hold whole quads.
+#include "mlp_common.h"
+
+namespace idn {
+namespace x6 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// (low half, high half) = (bf16(x0), bf16(x1)), round to nearest even
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+    return r;
+}
+// one packed word of each of the three pieces of two fp32 values (inputs are ordinary VALU results)
+__device__ __forceinline__ void split3(float x0, float x1, float& w1, float& w2, float& w3) {
+    const unsigned p1 = cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);   // exact
+    const unsigned p2 = cvt_pk_bf16(r0, r1);
+    r0 = r0 - __uint_as_float(p2 << 16);
+    r1 = r1 - __uint_as_float(p2 & 0xffff0000u);
+    w1 = __uint_as_float(p1);
+    w2 = __uint_as_float(p2);
+    w3 = __uint_as_float(cvt_pk_bf16(r0, r1));
+}
+
+// The pieces of one 32-channel tile of activations: piece q, k-step s (two 16-channel k-steps per tile).
+struct PTile6 {
+    f32x4 p[3][2];
+};
+// accumulator tile -> pieces.  Word W (0..7) = registers 2W, 2W+1 -> word W & 3 of k-step W >> 2 (element j of
+// k-step s in lane half h is channel 16 s + (j & 3) + 8 (j >> 2) + 4 h: how pack_bf16x6_kernel orders the weights).
+template <bool RELU>
+__device__ __forceinline__ void convert_tile(const f32x16& acc, PTile6& out) {
+    static_for<8>([&](auto W_) {
+        constexpr int w = decltype(W_)::value;
+        float x0 = acc[2 * w], x1 = acc[2 * w + 1];
+        if constexpr (RELU) {
+            x0 = relu1(x0);
+            x1 = relu1(x1);
+        }
+        float w1, w2, w3;
+        split3(x0, x1, w1, w2, w3);
+        out.p[0][w >> 2][w & 3] = w1;
+        out.p[1][w >> 2][w & 3] = w2;
+        out.p[2][w >> 2][w & 3] = w3;
+    });
+}
+
+// all but the newest `Newer` LDS reads of this wave have completed => the three fragments are valid
+template <int Newer>
+__device__ __forceinline__ void retire3(f32x4 (&v)[3]) {
+    if constexpr (Newer == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
+}
+
+constexpr int f0(int l) { return 2 * layer_f0(l); }   // quads: 4 fragments per k-step where layer_f0 counts 2
+
+// One layer, tile-major: for each n-tile t, KS k-steps of six piece products into O[t].  bget(ic<q>, ic<s>) =
+// piece q of k-step s of the layer's input.  The first fragments arrive in `pref` (issued by the layer before, or
+// here when the layer starts on a slice boundary) and leave in it for the next layer, VALID (retired): the
+// conversion between two layers is long, and a register with a read in flight must not be moved or spilled.
+template <int F0, int NT, int KS, class BGet, class Hook = NoHook>
+__device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGet&& bget, WStream& ws, FragReader& fr,
+                                          f32x4 (&pref)[3], Hook&& after_open = NoHook{}) {
+    constexpr int NP = NT * KS;
+    constexpr bool LAST = (F0 + 4 * NP == kX6UsedFrags);
+    static_assert(F0 % 4 == 0 && KS >= 4, "quads; the next tile's bias rides on the first four k-steps");
+    bias_tile(O[0], bias_half);
+    if constexpr (F0 % kSliceFrags == 0) {
+        ws.open_slice();
+        after_open();
+        static_for<3>([&](auto Q) { pref[decltype(Q)::value] = fr.template issue<F0 + decltype(Q)::value>(); });
+        retire3<0>(pref);
+    } else {
+        static_assert(std::is_same_v<std::decay_t<Hook>, NoHook>, "a hook needs a layer that starts on a slice boundary");
+    }
+    f32x4 a[3] = {pref[0], pref[1], pref[2]};
+    static_for<NP>([&](auto PI) {
+        constexpr int pi = decltype(PI)::value;
+        constexpr int t = pi / KS, s = pi % KS;
+        constexpr int f = F0 + 4 * pi;
+        constexpr bool next_crosses = ((f + 4) % kSliceFrags == 0);
+        constexpr bool has_next = !(LAST && pi + 1 == NP);
+        f32x4 n[3] = {a[0], a[1], a[2]};
+        if constexpr (!next_crosses && has_next) {
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
+            if constexpr (pi > 0) retire3<3>(a);   // (step 0's arrived retired)
+        } else {
+            if constexpr (pi > 0) retire3<0>(a);
+        }
+        ws.template step_piece<f>();
+        ws.template step_piece<f + 2>();
+        const f32x4 b1 = bget(ic<0>{}, ic<s>{}), b2 = bget(ic<1>{}, ic<s>{}), b3 = bget(ic<2>{}, ic<s>{});
+        O[t] = mfma_bf(a[0], b1, O[t]);   // w1 a1
+        O[t] = mfma_bf(a[0], b2, O[t]);   // w1 a2
+        O[t] = mfma_bf(a[1], b1, O[t]);   // w2 a1
+        if constexpr (t + 1 < NT && s < 4) bias_quad<s>(O[t + 1], bias_half + 32 * (t + 1));   // the next tile starts from its bias
+        O[t] = mfma_bf(a[1], b2, O[t]);   // w2 a2
+        O[t] = mfma_bf(a[0], b3, O[t]);   // w1 a3
+        O[t] = mfma_bf(a[2], b1, O[t]);   // w3 a1
+        if constexpr (next_crosses && pi + 1 < NP) {
+            ws.open_slice();
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
+        }
+        a[0] = n[0];
+        a[1] = n[1];
+        a[2] = n[2];
+    });
+    // hand over retired fragments (those of the next layer's first k-step, when this layer ends inside a slice)
+    if constexpr (!LAST && (F0 + 4 * NP) % kSliceFrags != 0) retire3<0>(a);
+    pref[0] = a[0];
+    pref[1] = a[1];
+    pref[2] = a[2];
+}
+
+template <int NT>
+__device__ __forceinline__ void convert_layer(const f32x16* O, PTile6* P) {
+    static_for<NT>([&](auto T) { convert_tile<true>(O[decltype(T)::value], P[decltype(T)::value]); });
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    float* bias_s = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < kBiasFloats; i += 256) bias_s[i] = a.bias[i];
+    __syncthreads();  // the bias block is read (by other waves) before the first slice barrier
+
+    Diag dg;
+    WStream ws;
+    ws.dg = &dg;
+    ws.init(a.wstream, kX6NumSlices, ring, tid, wave);
+    PeLane pln;
+    pln.init(h);
+
+    FragReader fr;
+    fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
+    fr.addr1 = fr.addr0 + 64 * kFragBytes;
+    const float* bias_h = bias_s + 4 * h;
+    const long ntiles = (a.n_points + 127) >> 7;
+
+    PointIn cur, nxt;
+    load_point<MODE>(a, blockIdx.x, wave, m, cur);
+    nxt = cur;
+    f32x4 pref[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long P = tile * 128 + wave * 32 + m;
+        const bool valid = P < a.n_points;
+        const long Pc = valid ? P : a.n_points - 1;
+
+        // ---- inputs: this lane's half of the 64 point features and 32 direction features, as pieces.
+        // Element j of k-step s, lane half h = feature 16 s + (j & 3) + 8 (j >> 2) + 4 h.
+        f32x4 pe_p[3][4], pd_p[3][2];
+        auto pack_feats = [&](auto&& feat, auto& out, auto NKS) {
+            static_for<decltype(NKS)::value>([&](auto S_) {
+                constexpr int s = decltype(S_)::value;
+                static_for<4>([&](auto W_) {
+                    constexpr int w = decltype(W_)::value;
+                    constexpr int j0 = 2 * w, j1 = 2 * w + 1;
+                    constexpr int k0 = 16 * s + (j0 & 3) + 8 * (j0 >> 2), k1 = 16 * s + (j1 & 3) + 8 * (j1 >> 2);
+                    float w1, w2, w3;
+                    split3(feat(ic<k0>{}), feat(ic<k1>{}), w1, w2, w3);
+                    out[0][s][w] = w1;
+                    out[1][s][w] = w2;
+                    out[2][s][w] = w3;
+                });
+            });
+        };
+        input_features<MODE>(a, Pc, h, pln, cur, [&](auto&& fpt, auto&& fdir) {
+            pack_feats(fpt, pe_p, ic<4>{});
+            pack_feats(fdir, pd_p, ic<2>{});
+        });
+
+        PTile6 Pt[8];
+        f32x16 O[8];
+        auto tiles = [&](auto Q, auto S_) {
+            constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
+            return Pt[s >> 1].p[q][s & 1];
+        };
+        // ---- pts_linears.0 : PE(64) -> 256
+        run_layer<f0(0), 8, 4>(O, bias_h + bias_off(0), [&](auto Q, auto S_) { return pe_p[decltype(Q)::value][decltype(S_)::value]; }, ws, fr, pref);
+        convert_layer<8>(O, Pt);
+        // ---- pts_linears.1..4 : one code instance (a 256 x 256 layer is four ring lengths of the stream)
+#pragma unroll 1
+        for (int l = 1; l <= 4; ++l) {
+            run_layer<f0(1), 8, 16>(O, bias_h + l * 256, tiles, ws, fr, pref);
+            convert_layer<8>(O, Pt);
+        }
+        // ---- pts_linears.5 : [PE(64) | 256] -> 256
+        run_layer<f0(5), 8, 20>(
+            O, bias_h + bias_off(5),
+            [&](auto Q, auto S_) {
+                constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
+                if constexpr (s < 4) return pe_p[q][s];
+                else return Pt[(s - 4) >> 1].p[q][(s - 4) & 1];
+            },
+            ws, fr, pref, [&]() { load_point<MODE>(a, tile + gridDim.x, wave, m, nxt); });
+        convert_layer<8>(O, Pt);
+        // ---- pts_linears.6, .7
+        run_layer<f0(6), 8, 16>(O, bias_h + bias_off(6), tiles, ws, fr, pref, [&]() { touch_point(nxt); });
+        convert_layer<8>(O, Pt);
+        run_layer<f0(7), 8, 16>(O, bias_h + bias_off(7), tiles, ws, fr, pref);
+        convert_layer<8>(O, Pt);
+        // ---- views_linears.0 (+ alpha_linear as channel 128): [256 | dirPE(32)] -> 160.
+        //      Tiles 0..3 are hidden units; tile 4 is never converted: its row 0 is sigma.
+        run_layer<f0(8), 5, 18>(
+            O, bias_h + bias_off(8),
+            [&](auto Q, auto S_) {
+                constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
+                if constexpr (s < 16) return Pt[s >> 1].p[q][s & 1];
+                else return pd_p[q][s - 16];
+            },
+            ws, fr, pref);
+        const float sigma = O[4][0];  // channel 128 = tile 4, register 0, lane half 0
+        convert_layer<4>(O, Pt);
+        // ---- views_linears.1, .2 : 128 -> 128
+        run_layer<f0(9), 4, 8>(O, bias_h + bias_off(9), tiles, ws, fr, pref);
+        convert_layer<4>(O, Pt);
+        run_layer<f0(10), 4, 8>(O, bias_h + bias_off(10), tiles, ws, fr, pref);
+        convert_layer<4>(O, Pt);
+        // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile)
+        run_layer<f0(11), 1, 8>(O, bias_h + bias_off(11), tiles, ws, fr, pref);
+        finish_pass<kX6UsedFrags, kX6StreamFrags>(ws);
+
+        if (valid && h == 0) {
+            f32x4 o;
+            o.x = O[0][0];
+            o.y = O[0][1];
+            o.z = O[0][2];
+            o.w = sigma;
+            *reinterpret_cast<f32x4*>(a.raw + P * 4) = o;
+        }
+        cur = nxt;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+}
+
+}  // namespace x6
+
+int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
+                      const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s) {
+    if (n_points <= 0) return IDN_OK;
+    static LaunchSetup setup;
+    int num_cu = 0;
+    if (int e = setup.get([]() -> int {
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeRays>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeX>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModePts>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            return IDN_OK;
+        }, &num_cu))
+        return e;
+    const int64_t ntiles = (n_points + 127) / 128;
+    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
+    MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, nullptr, 0};
+    ProfScope prof(s, n_points);
+    if (x)
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeX>), dim3(grid), dim3(256), kMlpLds, s, a);
+    else if (pts)
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModePts>), dim3(grid), dim3(256), kMlpLds, s, a);
+    else
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays>), dim3(grid), dim3(256), kMlpLds, s, a);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+}  // namespace idn

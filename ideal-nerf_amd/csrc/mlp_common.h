@@ -389,6 +389,26 @@ __device__ __forceinline__ void point_of(const PointIn& in, float (&p)[3], float
     }
 }
 
+// This lane's input features: calls use(fpt, fdir) with two providers, fpt(ic<K0>) / fdir(ic<K0>) =
+// feature K0 + 4h of gamma_10(point) / gamma_4(view direction) (zero beyond 63 / 27).
+template <int MODE, class Use>
+__device__ __forceinline__ void input_features(const MlpArgs& a, long Pc, int h, const PeLane& pln, const PointIn& in,
+                                               Use&& use) {
+    if constexpr (MODE == kModeX) {
+        const float* xr = a.x + Pc * (IDN_PTS_CH + IDN_VIEWS_CH) + 4 * h;
+        use([&](auto K) { constexpr int k = decltype(K)::value; return (k + 4 * h < IDN_PTS_CH) ? xr[k] : 0.0f; },
+            [&](auto K) { constexpr int k = decltype(K)::value; return (k + 4 * h < IDN_VIEWS_CH) ? xr[IDN_PTS_CH + k] : 0.0f; });
+    } else {
+        float p[3], v[3];
+        point_of<MODE>(in, p, v);
+        PeAxes axp, axd;
+        axp.init(p, h);
+        axd.init(v, h);
+        use([&](auto K) { return pe_slot<decltype(K)::value, 10>(axp, pln); },
+            [&](auto K) { return pe_slot<decltype(K)::value, 4>(axd, pln); });
+    }
+}
+
 // buffer descriptor over the 32 rows (LD floats each) a wave writes of a row-major matrix
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(float* first_row, int ld) {
     return __builtin_amdgcn_make_buffer_rsrc(first_row, 0, 32 * ld * 4, 0x00020000);

@@ -95,6 +95,42 @@ __global__ void pack_bf16x3_kernel(PackDesc d, uint4* out, int fmt) {
     out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// six-piece stream: fragment quad (4p .. 4p+3) of a tile = pieces p1, p2, p3 of one 16-channel k-step and a zero
+// fragment; same lane / element order as the bf16x3 stream.  p1 = bf16(w), p2 = bf16(w - p1), p3 = bf16(w - p1 - p2).
+__global__ void pack_bf16x6_kernel(PackDesc d, uint4* out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= kX6StreamFrags * 64) return;
+    const int f = gid >> 6, lane = gid & 63;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    const int part = f & 3;
+    if (f < kX6UsedFrags && part < 3) {
+        int l = 0;
+        while (l + 1 < kNumLayers && f >= 2 * d.L[l + 1].f0) ++l;
+        const PackLayer& L = d.L[l];
+        const int rel = (f - 2 * L.f0) >> 2, ksn = L.kg / 2;   // k-step index within the layer, tile-major
+        const int t = rel / ksn, ks = rel - t * ksn;
+        const int n = 32 * t + (lane & 31), h = lane >> 5;
+        const int ks0 = L.kg0 >> 1;
+        const int src = ks < ks0 ? 0 : 1;
+        const int kbase = 16 * (src ? ks - ks0 : ks) + 4 * h;
+        for (int j = 0; j < 8; ++j) {
+            const int k = kbase + (j & 3) + 8 * (j >> 2);
+            float v = 0.f;
+            if (k < L.kvalid[src]) {
+                if (n < L.rows) v = L.w[(long)n * L.ld + L.col0[src] + k];
+                else if (L.w_extra && n == L.extra_at && src == 0) v = L.w_extra[k];
+            }
+            const unsigned p1 = bf16_rne(v);
+            const float r1 = v - __uint_as_float(p1 << 16);
+            const unsigned p2 = bf16_rne(r1);
+            const float r2 = r1 - __uint_as_float(p2 << 16);
+            const unsigned bits = part == 0 ? p1 : (part == 1 ? p2 : bf16_rne(r2));
+            w[j >> 1] |= bits << (16 * (j & 1));
+        }
+    }
+    out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // plain-bf16 stream: one fragment per (tile, k-step): 8 bf16 per lane, same channel order
 __global__ void pack_bf16_kernel(PackDesc d, uint4* out) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,6 +167,15 @@ int launch_pack_bf16(const idn_facenerf_params& p, float* packed, hipStream_t s)
     fill_pack_desc(p, d);
     const int total = kPlainStreamFrags * 64;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d, reinterpret_cast<uint4*>(packed));
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+int launch_pack_bf16x6(const idn_facenerf_params& p, float* packed, hipStream_t s) {
+    PackDesc d;
+    fill_pack_desc(p, d);
+    const int total = kX6StreamFrags * 64;
+    hipLaunchKernelGGL(pack_bf16x6_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d, reinterpret_cast<uint4*>(packed));
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

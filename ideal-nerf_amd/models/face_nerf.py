@@ -10,9 +10,10 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .._lib import IDN_PREC_BF16, IDN_PREC_BF16X3, IDN_PREC_F32, IDN_PREC_FP16X3
+from .._lib import IDN_PREC_BF16, IDN_PREC_BF16X3, IDN_PREC_BF16X6, IDN_PREC_F32, IDN_PREC_FP16X3
 
-PRECISIONS = {"f32": IDN_PREC_F32, "bf16x3": IDN_PREC_BF16X3, "bf16": IDN_PREC_BF16, "fp16x3": IDN_PREC_FP16X3}
+PRECISIONS = {"f32": IDN_PREC_F32, "bf16x3": IDN_PREC_BF16X3, "bf16": IDN_PREC_BF16, "fp16x3": IDN_PREC_FP16X3,
+              "bf16x6": IDN_PREC_BF16X6}
 _default_precision = ["f32"]
 
 

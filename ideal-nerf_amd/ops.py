@@ -71,7 +71,7 @@ class _Launch:
 
 
 def _precision(precision):
-    if precision not in (_lib.IDN_PREC_F32, _lib.IDN_PREC_BF16X3, _lib.IDN_PREC_BF16, _lib.IDN_PREC_FP16X3):
+    if precision not in (_lib.IDN_PREC_F32, _lib.IDN_PREC_BF16X3, _lib.IDN_PREC_BF16, _lib.IDN_PREC_FP16X3, _lib.IDN_PREC_BF16X6):
         raise IdealNerfError(f"unknown precision code {precision}")
     return int(precision)
 

@@ -54,6 +54,8 @@ extern "C" {
 #define IDN_PREC_BF16 2   /* plain bf16 MFMA, fp32 accumulate (BASELINE config 5 only) */
 #define IDN_PREC_FP16X3 3 /* 3 fp16 MFMAs per product (11+11 significand bits per operand): ~5e-7 on the
                              network output at the bf16x3 speed; activations must stay below 6.5e4 */
+#define IDN_PREC_BF16X6 4 /* 6 bf16 MFMAs per product: weights and activations as the exact sum of three bf16 pieces
+                             (24 significand bits, fp32's range), fp32 accumulate: fp32-grade (error <= 2^-23 per product) */
 
 int idealnerf_version(void);
 const char* idealnerf_last_error(void);

@@ -1486,3 +1486,78 @@ def test_fp16x3_saturates_finitely_outside_fp16_range(idn, dev):
     assert rel_err(outs["f32"], ref) < 1e-5 and rel_err(outs["bf16x3"], ref) < 1e-4
     assert bool(torch.isfinite(outs["fp16x3"]).all())
     assert rel_err(outs["fp16x3"], ref) > 1e-3     # outside its domain, and visibly so
+
+
+# --------------------------------------------------------------------------- six-piece bf16 arithmetic mode
+BF16X6 = 4  # IDN_PREC_BF16X6
+
+
+def test_bf16x6_facenerf_golden_ragged_and_range(idn, dev, golden):
+    """Six bf16 piece products per fp32 product (weights and activations as the exact sum of three bf16 pieces):
+    the fp32 kernel's error on the reference's golden vectors, on ragged point counts, and -- unlike fp16x3 -- on
+    activations far outside fp16's range (bf16 pieces have fp32's exponent range)."""
+    g = golden("facenerf")
+    for name, v in (("c235", dict(dim_aud=64, dim_expr=76, dim_latent=32)), ("c169", dict(dim_aud=106, dim_expr=0, dim_latent=0))):
+        dims = oracle.facenerf_dims(**v)
+        sd = {k: t.to(dev).contiguous() for k, t in oracle.xavier_facenerf_params(11, dims).items()}
+        ps = idn.ops.params_struct(sd, dims["dim_aud"], dims["dim_expr"], dims["dim_latent"])
+        opt = lambda k: T(g[k]).to(dev) if k in g else None
+        folded = idn.ops.fold_conditioning(ps, T(g[name + "_aud"]).to(dev), opt(name + "_expr"), opt(name + "_latent"), dev)
+        x = T(g[name + "_x"]).to(dev)
+        out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, BF16X6), folded, x, BF16X6)
+        out32 = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, 0), folded, x, 0)
+        e6, e32 = rel_err(out, g[name + "_out"]), rel_err(out32, g[name + "_out"])
+        print(f"\nbf16x6 FaceNeRF {name}: max rel err vs reference = {e6:.2e} (the fp32 kernel: {e32:.2e})")
+        assert e6 < 5e-6, name
+    dims = oracle.facenerf_dims()
+    params = scale_sigma(oracle.xavier_facenerf_params(5, dims), 30.0, 0.1)
+    for n in (1, 33, 130, 4099):
+        rs = np.random.RandomState(n)
+        x = T(rs.uniform(-1, 1, size=(n, 90)).astype(np.float32))
+        aud, expr, lat = (T(rs.standard_normal(k).astype(np.float32)) for k in (64, 76, 32))
+        with torch.no_grad():
+            ref = oracle.facenerf_forward(params, x, aud, expr, lat, dims)
+        sd = {k: t.to(dev).contiguous() for k, t in params.items()}
+        ps = idn.ops.params_struct(sd, 64, 76, 32)
+        out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, BF16X6),
+                                   idn.ops.fold_conditioning(ps, aud.to(dev), expr.to(dev), lat.to(dev), dev), x.to(dev), BF16X6)
+        assert out.shape == (n, 4) and rel_err(out, ref) < 1e-5, n
+    # first hidden layer ~1e5: fp16x3 saturates here (test_fp16x3_saturates_finitely_outside_fp16_range); this mode does not care
+    params = oracle.xavier_facenerf_params(9, dims)
+    params["pts_linears.0.weight"] = params["pts_linears.0.weight"] * 3e5
+    rs = np.random.RandomState(0)
+    x = T(rs.uniform(-1, 1, size=(256, 90)).astype(np.float32))
+    aud, expr, lat = (T(rs.standard_normal(k).astype(np.float32)) for k in (64, 76, 32))
+    with torch.no_grad():
+        ref = oracle.facenerf_forward(params, x, aud, expr, lat, dims)
+    sd = {k: t.to(dev).contiguous() for k, t in params.items()}
+    ps = idn.ops.params_struct(sd, 64, 76, 32)
+    folded = idn.ops.fold_conditioning(ps, aud.to(dev), expr.to(dev), lat.to(dev), dev)
+    out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, BF16X6), folded, x.to(dev), BF16X6)
+    assert rel_err(out, ref) < 1e-5
+
+
+def test_bf16x6_render_frame32_golden(idn, dev, golden):
+    """Whole render path in the six-piece mode against the reference's golden frame: RGB inside the budget, the
+    importance-sample indices flipping at the fp32 kernel's rate."""
+    g = golden("frame32")
+    dims = oracle.facenerf_dims()
+    syn = oracle.synthetic_frame(32, 32, seed=0, dims=dims)
+    cond = [t.to(dev) for t in (syn["aud"], syn["expr"], syn["latent"])]
+    res = {}
+    for code in (BF16X6, 0):
+        packs = []
+        for seed in (2, 3):
+            sd = {k: t.to(dev).contiguous() for k, t in scale_sigma(oracle.xavier_facenerf_params(seed, dims)).items()}
+            ps = idn.ops.params_struct(sd, 64, 76, 32)
+            packs.append((idn.ops.pack_weights(ps, dev, code), idn.ops.fold_conditioning(ps, *cond, dev)))
+        rays = idn.ops.frame_rays(syn["c2w"], 32, 32, syn["focal"], NEAR, FAR, device=dev)
+        out = idn.ops.render_rays_fwd(rays, syn["bc"].reshape(-1, 3).to(dev), packs[0][0], packs[0][1], packs[1][0], packs[1][1],
+                                      torch.linspace(0.0, 1.0, 64).to(dev), torch.linspace(0.0, 1.0, 128).to(dev), 128,
+                                      taps=True, precision=code)
+        res[code] = (rel_err(out["rgb_map"], g["rgb"].reshape(-1, 3)), rel_err(out["rgb0"], g["rgb0"].reshape(-1, 3)),
+                     float((out["tap_inds"].cpu().numpy() != g["tap_inds"].astype(np.int64)).mean()))
+    print(f"\nbf16x6 frame32: rgb err {res[BF16X6][0]:.2e}, rgb0 {res[BF16X6][1]:.2e}, index flip rate {res[BF16X6][2]:.2e} "
+          f"(the fp32 kernel: {res[0][0]:.2e}, {res[0][1]:.2e}, {res[0][2]:.2e})")
+    assert res[BF16X6][0] < RGB_TOL and res[BF16X6][1] < 1e-5
+    assert res[BF16X6][2] < FLIP_TOL
