@@ -39,7 +39,8 @@ def mode_peaks():
     # peak is total FLOP / (coarse FLOP / fp32 peak + fine FLOP / (bf16 peak / 3)), so frac = ideal time / actual
     mixed_peak = 1.0 / (0.25 / PEAK_F32_MFMA_TFLOPS + 0.75 / (PEAK_BF16_MFMA_TFLOPS / 3.0))
     return {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3.0,
-            "bf16": PEAK_BF16_MFMA_TFLOPS, "mixed": mixed_peak}   # the dense fp16 and bf16 MFMA peaks are equal on gfx950
+            "bf16": PEAK_BF16_MFMA_TFLOPS, "mixed": mixed_peak,   # the dense fp16 and bf16 MFMA peaks are equal on gfx950
+            "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0}                # six bf16 piece products per algorithmic product
 
 
 def profile_kinds(lib):
@@ -449,14 +450,15 @@ def main():
     ap.add_argument("--soak", action="store_true",
                     help="compare every timed frame with the first one bit for bit (the path is deterministic: a mismatch is "
                          "a race); reported as `soak_mismatched_frames`")
-    ap.add_argument("--precision", choices=["f32", "mixed", "fp16x3", "bf16x3", "bf16"], default=os.environ.get("IDN_PRECISION", "f32"),
+    ap.add_argument("--precision", choices=["f32", "mixed", "fp16x3", "bf16x3", "bf16", "bf16x6"], default=os.environ.get("IDN_PRECISION", "f32"),
                     help="arithmetic of the MLP contraction.  f32 (default, the headline line): exact fp32 MFMA chains, "
                          "RGB within 1e-6..1e-5 of the reference.  bf16x3: three bf16 MFMAs per product, 3.4x faster, "
                          "within the 1e-4 RGB budget on the reference's golden frame and this scene, but sharp scenes "
                          "amplify its 1.5e-5 through the importance sampling (DESIGN.md section 3) -- measured beside "
                          "the headline as `bf16x3_mode`.  mixed: fp32 coarse network (it drives the sampling) + bf16x3 fine "
                          "network, ~2x the fp32 speed inside the 1e-4 budget, measured as `mixed_mode`.  bf16 (plain, ~1e-2): "
-                         "BASELINE config 5's PSNR criterion only")
+                         "BASELINE config 5's PSNR criterion only.  bf16x6: weights and activations as three bf16 pieces each, six "
+                         "MFMAs per product: the fp32 kernel's parity on the bf16 pipe, measured as `bf16x6_mode`")
     ap.add_argument("--workload", choices=["frame", "train", "torso", "rendezvous"], default="frame",
                     help="frame = BASELINE configs[1] (default, the headline metric); train = configs[2] train step; "
                          "torso = configs[4] head+torso composite frames, plain bf16, frame-parallel")
@@ -557,12 +559,13 @@ def main():
                  "bf16x3": "idn::mlp_bf16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 bf16 MFMAs per product)",
                  "bf16": "idn::mlp_bf16_kernel<kModeRays> (fused PE + FaceNeRF MLP, plain bf16 MFMA)",
                  "fp16x3": "idn::mlp_fp16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 fp16 MFMAs per product)",
-                 "mixed": "idn::mlp_f32_kernel (coarse network) + idn::mlp_bf16x3_kernel (fine network); blended peak"}[args.precision]
+                 "mixed": "idn::mlp_f32_kernel (coarse network) + idn::mlp_bf16x3_kernel (fine network); blended peak",
+                 "bf16x6": "idn::x6::mlp_bf16x6_kernel<kModeRays> (fused PE + FaceNeRF MLP, 6 bf16 piece products per fp32 product)"}[args.precision]
         res = {
             "metric": "ray-samples/sec (64+128 pts, 512x512), whole job", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "ranks": world, "backend": backend,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)", "mixed": "f32 coarse network + bf16x3 fine network", "fp16x3": "fp16x3 (fp32 in/out, fp32 accumulate)"}[args.precision], "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)", "mixed": "f32 coarse network + bf16x3 fine network", "fp16x3": "fp16x3 (fp32 in/out, fp32 accumulate)", "bf16x6": "bf16x6 (operands as three bf16 pieces = 24 significand bits, fp32 accumulate: fp32-grade)"}[args.precision], "data": "synthetic",
             "per_gpu": value / world, "rays_per_s": value / (S + S + Ni),
             **({"soak_mismatched_frames": int(mismatched.item())} if args.soak else {}),
             "config": {"workload": f"BASELINE configs[1]: May HeadNeRF {H}x{W} full-frame render, N_sample=64 "
@@ -589,7 +592,9 @@ def main():
                               "bf16x3; priced against the blended peak of the two kernels"}
             notes["fp16x3"] = ("IDN_PREC_FP16X3: 3 x v_mfma_f32_32x32x16_f16 per product (11+11 significand bits per operand), "
                                "fp32 accumulate; priced against the fp16 (= bf16) peak / 3")
-            for other in (["fp16x3", "mixed", "bf16x3"] if args.precision == "f32" else ["f32"]):
+            notes["bf16x6"] = ("IDN_PREC_BF16X6: weights and activations as the exact sum of three bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per "
+                               "product, fp32 accumulate: fp32-grade (<= 2^-23 per product), fp32's range; priced against bf16 peak / 6")
+            for other in (["bf16x6", "fp16x3", "mixed", "bf16x3"] if args.precision == "f32" else ["f32"]):
                 set_mode(other)
                 pko_c, pko_f = coarse.packed_weights(), fine.packed_weights()
                 code_c, code_f = coarse.prec_code, fine.prec_code
