@@ -9,6 +9,7 @@ which stay ordinary autograd modules) and ``latent_code``.  Sampled depths are d
 exactly as upstream (:345); ``expr`` is data.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -45,16 +46,25 @@ def _grads_struct(grads):
     return g
 
 
+# Arithmetic of the training forward: "bf16x6" (six bf16 piece products per fp32 product, weights and activations as
+# three bf16 pieces: fp32-grade, 1.6x the fp32 pipe) or "f32" (fp32 MFMA).  The backward's pipes are a property of the
+# library build.
+TRAIN_PRECISION = os.environ.get("IDN_TRAIN_PRECISION", "bf16x6")
+
+
 def _train_query(net, folded, rays, z):
     lib = _lib.load()
     ops._shape(z, "z", None, None)
     n, S = z.shape
     ops._shape(rays, "rays", n, ops.RAY_FLOATS)
-    packed = net.packed_weights("f32")
+    if TRAIN_PRECISION not in ("f32", "bf16x6"):
+        raise _lib.IdealNerfError(f"IDN_TRAIN_PRECISION must be f32 or bf16x6 (got {TRAIN_PRECISION!r})")
+    packed = net.packed_weights(TRAIN_PRECISION)
+    code = _lib.IDN_PREC_F32 if TRAIN_PRECISION == "f32" else _lib.IDN_PREC_BF16X6
     with ops._Launch(packed, folded, rays, z) as L:
         raw = torch.empty((n, S, 4), dtype=torch.float32, device=z.device)
         acts = torch.empty(lib.idealnerf_train_acts_floats(n * S), dtype=torch.float32, device=z.device)
-        check(lib.idealnerf_query_rays_train_fwd(ops._ptr(packed, "packed"), ops._ptr(folded, "folded"), IDN_PREC_F32,
+        check(lib.idealnerf_query_rays_train_fwd(ops._ptr(packed, "packed"), ops._ptr(folded, "folded"), code,
                                                  ops._ptr(rays, "rays"), ops._ptr(z, "z"), n, S, raw.data_ptr(),
                                                  acts.data_ptr(), L.stream))
     return raw, acts

@@ -21,9 +21,9 @@ static int check_precision(int precision) {
         return IDN_OK;
     return fail(IDN_EUNSUPPORTED, "precision %d is unknown (IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16, IDN_PREC_FP16X3, IDN_PREC_BF16X6)", precision);
 }
-static int check_precision_f32(int precision) {
-    if (precision == IDN_PREC_F32) return IDN_OK;
-    return fail(IDN_EUNSUPPORTED, "the training path is built for IDN_PREC_F32 only (got %d)", precision);
+static int check_precision_train(int precision) {
+    if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X6) return IDN_OK;
+    return fail(IDN_EUNSUPPORTED, "the training path runs fp32-grade arithmetic only: IDN_PREC_F32 or IDN_PREC_BF16X6 (got %d)", precision);
 }
 
 int launch_mlp(int precision, const float* packed, const float* folded, const float* x, const float* rays,
@@ -230,7 +230,7 @@ size_t idealnerf_train_acts_floats(int64_t n_points) {
 int idealnerf_query_rays_train_fwd(const float* packed, const float* folded, int precision, const float* rays,
                                    const float* z, int64_t n_rays, int n_samples, float* raw, float* acts,
                                    void* stream) {
-    if (int e = check_precision_f32(precision)) return e;
+    if (int e = check_precision_train(precision)) return e;
     if (n_rays < 0 || n_samples < 1) return fail(IDN_EINVAL, "bad sizes");
     if (n_rays == 0) return IDN_OK;
     if (!packed || !folded || !rays || !z || !raw || !acts) return fail(IDN_EINVAL, "NULL pointer");
@@ -240,6 +240,8 @@ int idealnerf_query_rays_train_fwd(const float* packed, const float* folded, int
         for (int i = 0; i < kActCount; ++i)
             IDN_HIP_CHECK(hipMemsetAsync(acts + (size_t)act_off(i) * p_pad + (size_t)n * act_width(i), 0,
                                          (size_t)(p_pad - n) * act_width(i) * sizeof(float), (hipStream_t)stream));
+    if (precision == IDN_PREC_BF16X6)
+        return launch_mlp_bf16x6(packed, folded, nullptr, rays, z, nullptr, nullptr, n, n_samples, raw, (hipStream_t)stream, acts, p_pad);
     return launch_mlp_f32(packed, folded, nullptr, rays, z, nullptr, nullptr, n, n_samples, raw, (hipStream_t)stream,
                           acts, p_pad);
 }

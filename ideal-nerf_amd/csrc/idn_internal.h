@@ -181,7 +181,8 @@ int launch_pack_f32(const idn_facenerf_params& p, float* packed, hipStream_t s);
 int launch_pack_bf16x3(const idn_facenerf_params& p, float* packed, hipStream_t s, int fmt = 0);  // fmt 1: fp16 halves
 int launch_pack_bf16x6(const idn_facenerf_params& p, float* packed, hipStream_t s);
 int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
-                      const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
+                      const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s,
+                      float* acts = nullptr, int64_t p_pad = 0);   // acts != null: the training forward (saves activations + ReLU masks)
 int launch_pack_bf16(const idn_facenerf_params& p, float* packed, hipStream_t s);
 int launch_mlp_bf16(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
                     const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s);
@@ -247,6 +248,11 @@ int launch_pack_f32_bwd(const idn_facenerf_params& p, float* packed_bwd, hipStre
 // acts: the forward's activation slab, dv2/dv1: [p_pad, 128], da[l]: [p_pad, 256] = delta of pts_linears.l
 int launch_delta_chain(const float* packed_bwd, const float* acts, int64_t p_pad, const float* d_rgb, float* dv0,
                        float* dv2, float* dv1, float* const da[8], hipStream_t s);
+// the same chain as six bf16 piece products per fp32 product (its own transposed stream, twice the fragments)
+size_t bwd_stream_floats_x6();
+int launch_pack_bf16x6_bwd(const idn_facenerf_params& p, float* packed_bwd, hipStream_t s);
+int launch_delta_chain_x6(const float* packed_bwd, const float* acts, int64_t p_pad, const float* d_rgb, float* dv0,
+                          float* dv2, float* dv1, float* const da[8], hipStream_t s);
 size_t bwd_workspace_bytes(int64_t n_points);
 size_t dw_gemm_workspace_bytes();
 int launch_dw_gemm(const float* delta, int ld_delta, const float* acts, int ld_acts, int64_t rows, float* dW, float* db, int pipe,

@@ -17,62 +17,10 @@
 //
 // Weight stream: per (n-tile, 16-channel k-step) a QUAD of fragments (p1, p2, p3, zero): twice the fragments of the
 // bf16x3 stream, so every layer starts where it does there modulo the ring, and slices hold whole quads.
-#include "mlp_common.h"
+#include "mlp_x6.h"
 
 namespace idn {
 namespace x6 {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// (low half, high half) = (bf16(x0), bf16(x1)), round to nearest even
-__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
-    return r;
-}
-// one packed word of each of the three pieces of two fp32 values (inputs are ordinary VALU results)
-__device__ __forceinline__ void split3(float x0, float x1, float& w1, float& w2, float& w3) {
-    const unsigned p1 = cvt_pk_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);   // exact
-    const unsigned p2 = cvt_pk_bf16(r0, r1);
-    r0 = r0 - __uint_as_float(p2 << 16);
-    r1 = r1 - __uint_as_float(p2 & 0xffff0000u);
-    w1 = __uint_as_float(p1);
-    w2 = __uint_as_float(p2);
-    w3 = __uint_as_float(cvt_pk_bf16(r0, r1));
-}
-
-// The pieces of one 32-channel tile of activations: piece q, k-step s (two 16-channel k-steps per tile).
-struct PTile6 {
-    f32x4 p[3][2];
-};
-// accumulator tile -> pieces.  Word W (0..7) = registers 2W, 2W+1 -> word W & 3 of k-step W >> 2 (element j of
-// k-step s in lane half h is channel 16 s + (j & 3) + 8 (j >> 2) + 4 h: how pack_bf16x6_kernel orders the weights).
-template <bool RELU>
-__device__ __forceinline__ void convert_tile(const f32x16& acc, PTile6& out) {
-    static_for<8>([&](auto W_) {
-        constexpr int w = decltype(W_)::value;
-        float x0 = acc[2 * w], x1 = acc[2 * w + 1];
-        if constexpr (RELU) {
-            x0 = relu1(x0);
-            x1 = relu1(x1);
-        }
-        float w1, w2, w3;
-        split3(x0, x1, w1, w2, w3);
-        out.p[0][w >> 2][w & 3] = w1;
-        out.p[1][w >> 2][w & 3] = w2;
-        out.p[2][w >> 2][w & 3] = w3;
-    });
-}
-
-// all but the newest `Newer` LDS reads of this wave have completed => the three fragments are valid
-template <int Newer>
-__device__ __forceinline__ void retire3(f32x4 (&v)[3]) {
-    if constexpr (Newer == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
-    else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
-}
 
 constexpr int f0(int l) { return 2 * layer_f0(l); }   // quads: 4 fragments per k-step where layer_f0 counts 2
 
@@ -134,12 +82,27 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
     pref[2] = a[2];
 }
 
-template <int NT>
-__device__ __forceinline__ void convert_layer(const f32x16* O, PTile6* P) {
-    static_for<NT>([&](auto T) { convert_tile<true>(O[decltype(T)::value], P[decltype(T)::value]); });
+// End of a layer: the NT accumulator tiles are ReLU'd and split into the piece registers (the next layer's input).
+// Training (SAVE): the sign bits of the pre-activations go into the layer's mask words and the post-ReLU values into
+// this lane's row of the layer's activation matrix (`row` = its first float + 4 h; register 4 q + j of tile t is
+// channel 32 t + 8 q + 4 h + j, so a quad of registers is 16 contiguous bytes of the row).
+template <int NT, bool SAVE>
+__device__ __forceinline__ void convert_layer(const f32x16* O, PTile6* P, float* row = nullptr, uint32_t* mk = nullptr) {
+    static_for<NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        if constexpr (SAVE) {
+            collect_signs<t>(O[t], mk);
+            static_for<4>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) =
+                    f32x4{relu1(O[t][4 * q]), relu1(O[t][4 * q + 1]), relu1(O[t][4 * q + 2]), relu1(O[t][4 * q + 3])};
+            });
+        }
+        convert_tile<true>(O[t], P[t]);
+    });
 }
 
-template <int MODE>
+template <int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
@@ -178,40 +141,74 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
         // ---- inputs: this lane's half of the 64 point features and 32 direction features, as pieces.
         // Element j of k-step s, lane half h = feature 16 s + (j & 3) + 8 (j >> 2) + 4 h.
         f32x4 pe_p[3][4], pd_p[3][2];
-        auto pack_feats = [&](auto&& feat, auto& out, auto NKS) {
-            static_for<decltype(NKS)::value>([&](auto S_) {
-                constexpr int s = decltype(S_)::value;
-                static_for<4>([&](auto W_) {
-                    constexpr int w = decltype(W_)::value;
-                    constexpr int j0 = 2 * w, j1 = 2 * w + 1;
-                    constexpr int k0 = 16 * s + (j0 & 3) + 8 * (j0 >> 2), k1 = 16 * s + (j1 & 3) + 8 * (j1 >> 2);
-                    float w1, w2, w3;
-                    split3(feat(ic<k0>{}), feat(ic<k1>{}), w1, w2, w3);
-                    out[0][s][w] = w1;
-                    out[1][s][w] = w2;
-                    out[2][s][w] = w3;
+        {
+            // feature 8 g + 4 h + j of the point (g < 8) and of the direction (g < 4)
+            float pe_f[8][4], pd_f[4][4];
+            input_features<MODE>(a, Pc, h, pln, cur, [&](auto&& fpt, auto&& fdir) {
+                static_for<8>([&](auto G) {
+                    static_for<4>([&](auto J) {
+                        constexpr int g = decltype(G)::value, j = decltype(J)::value;
+                        pe_f[g][j] = fpt(ic<8 * g + j>{});
+                        if constexpr (g < 4) pd_f[g][j] = fdir(ic<8 * g + j>{});
+                    });
                 });
             });
-        };
-        input_features<MODE>(a, Pc, h, pln, cur, [&](auto&& fpt, auto&& fdir) {
-            pack_feats(fpt, pe_p, ic<4>{});
-            pack_feats(fdir, pd_p, ic<2>{});
-        });
+            if constexpr (SAVE) {   // every row of the slab, padding rows included (they repeat the last point)
+                float* x0 = a.acts + act_off(kActX0) * a.p_pad + P * 64 + 4 * h;
+                float* dr = a.acts + act_off(kActDir) * a.p_pad + P * 64 + 4 * h;
+                static_for<8>([&](auto G) {
+                    constexpr int g = decltype(G)::value;
+                    *reinterpret_cast<f32x4*>(x0 + 8 * g) = f32x4{pe_f[g][0], pe_f[g][1], pe_f[g][2], pe_f[g][3]};
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (g < 4) v = f32x4{pd_f[g][0], pd_f[g][1], pd_f[g][2], pd_f[g][3]};
+                    *reinterpret_cast<f32x4*>(dr + 8 * g) = v;
+                });
+            }
+            // word w of k-step s = elements (2 w, 2 w + 1) = features 16 s + 8 (w >> 1) + 2 (w & 1) + {0, 1} (+ 4 h)
+            auto pack_feats = [&](auto& f, auto& out, auto NKS) {
+                static_for<decltype(NKS)::value>([&](auto S_) {
+                    constexpr int s = decltype(S_)::value;
+                    static_for<4>([&](auto W_) {
+                        constexpr int w = decltype(W_)::value;
+                        float w1, w2, w3;
+                        split3(f[2 * s + (w >> 1)][2 * (w & 1)], f[2 * s + (w >> 1)][2 * (w & 1) + 1], w1, w2, w3);
+                        out[0][s][w] = w1;
+                        out[1][s][w] = w2;
+                        out[2][s][w] = w3;
+                    });
+                });
+            };
+            pack_feats(pe_f, pe_p, ic<4>{});
+            pack_feats(pd_f, pd_p, ic<2>{});
+        }
 
         PTile6 Pt[8];
         f32x16 O[8];
+        uint32_t mk[4] = {0u, 0u, 0u, 0u};   // SAVE: the current layer's ReLU mask bits
+        // SAVE: record layer `idx` of the activation slab (LD floats per row) and its mask words (layer id idx - kActA1)
+        auto finish_layer = [&](auto NTc, auto LDc, int idx) {
+            constexpr int NT = decltype(NTc)::value, LD = decltype(LDc)::value;
+            if constexpr (SAVE) {
+                convert_layer<NT, true>(O, Pt, a.acts + (long)act_off(idx) * a.p_pad + P * LD + 4 * h, mk);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(idx - kActA1, a.p_pad, tile * 4 + wave, lane);
+                *mp = u32x4{mk[0], mk[1], mk[2], mk[3]};
+            } else {
+                convert_layer<NT, false>(O, Pt);
+            }
+        };
         auto tiles = [&](auto Q, auto S_) {
             constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
             return Pt[s >> 1].p[q][s & 1];
         };
         // ---- pts_linears.0 : PE(64) -> 256
         run_layer<f0(0), 8, 4>(O, bias_h + bias_off(0), [&](auto Q, auto S_) { return pe_p[decltype(Q)::value][decltype(S_)::value]; }, ws, fr, pref);
-        convert_layer<8>(O, Pt);
+        finish_layer(ic<8>{}, ic<256>{}, kActA1 + 0);
         // ---- pts_linears.1..4 : one code instance (a 256 x 256 layer is four ring lengths of the stream)
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
             run_layer<f0(1), 8, 16>(O, bias_h + l * 256, tiles, ws, fr, pref);
-            convert_layer<8>(O, Pt);
+            finish_layer(ic<8>{}, ic<256>{}, kActA1 + l);
         }
         // ---- pts_linears.5 : [PE(64) | 256] -> 256
         run_layer<f0(5), 8, 20>(
@@ -222,12 +219,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
                 else return Pt[(s - 4) >> 1].p[q][(s - 4) & 1];
             },
             ws, fr, pref, [&]() { load_point<MODE>(a, tile + gridDim.x, wave, m, nxt); });
-        convert_layer<8>(O, Pt);
+        finish_layer(ic<8>{}, ic<256>{}, kActA1 + 5);
         // ---- pts_linears.6, .7
         run_layer<f0(6), 8, 16>(O, bias_h + bias_off(6), tiles, ws, fr, pref, [&]() { touch_point(nxt); });
-        convert_layer<8>(O, Pt);
+        finish_layer(ic<8>{}, ic<256>{}, kActA1 + 6);
         run_layer<f0(7), 8, 16>(O, bias_h + bias_off(7), tiles, ws, fr, pref);
-        convert_layer<8>(O, Pt);
+        finish_layer(ic<8>{}, ic<256>{}, kActA1 + 7);
         // ---- views_linears.0 (+ alpha_linear as channel 128): [256 | dirPE(32)] -> 160.
         //      Tiles 0..3 are hidden units; tile 4 is never converted: its row 0 is sigma.
         run_layer<f0(8), 5, 18>(
@@ -239,12 +236,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
             },
             ws, fr, pref);
         const float sigma = O[4][0];  // channel 128 = tile 4, register 0, lane half 0
-        convert_layer<4>(O, Pt);
+        finish_layer(ic<4>{}, ic<128>{}, kActV1);
         // ---- views_linears.1, .2 : 128 -> 128
         run_layer<f0(9), 4, 8>(O, bias_h + bias_off(9), tiles, ws, fr, pref);
-        convert_layer<4>(O, Pt);
+        finish_layer(ic<4>{}, ic<128>{}, kActV1 + 1);
         run_layer<f0(10), 4, 8>(O, bias_h + bias_off(10), tiles, ws, fr, pref);
-        convert_layer<4>(O, Pt);
+        finish_layer(ic<4>{}, ic<128>{}, kActV1 + 2);
         // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile)
         run_layer<f0(11), 1, 8>(O, bias_h + bias_off(11), tiles, ws, fr, pref);
         finish_pass<kX6UsedFrags, kX6StreamFrags>(ws);
@@ -266,30 +263,36 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
 }  // namespace x6
 
 int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
-                      const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s) {
+                      const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s,
+                      float* acts, int64_t p_pad) {
     if (n_points <= 0) return IDN_OK;
+    if (acts && (x || pts)) return fail(IDN_EUNSUPPORTED, "the activation-saving forward takes rays");
     static LaunchSetup setup;
     int num_cu = 0;
     if (int e = setup.get([]() -> int {
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeRays>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeRays, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeX>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeRays, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModePts>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeX, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModePts, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
             return IDN_OK;
         }, &num_cu))
         return e;
     const int64_t ntiles = (n_points + 127) / 128;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
-    MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, nullptr, 0};
-    ProfScope prof(s, n_points);
+    MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, acts, (long)p_pad};
+    ProfScope prof(s, n_points, acts ? IDN_PROF_MLP_FWD_SAVE : IDN_PROF_MLP_FWD);
     if (x)
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeX>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeX, false>), dim3(grid), dim3(256), kMlpLds, s, a);
     else if (pts)
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModePts>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModePts, false>), dim3(grid), dim3(256), kMlpLds, s, a);
+    else if (acts)
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, true>), dim3(grid), dim3(256), kMlpLds, s, a);
     else
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, false>), dim3(grid), dim3(256), kMlpLds, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

@@ -409,6 +409,15 @@ __device__ __forceinline__ void input_features(const MlpArgs& a, long Pc, int h,
     }
 }
 
+// Sign bits of a tile's 16 pre-activations pushed into mask dword T / 2 (idn_internal.h "ReLU masks"):
+// one v_alignbit per value, (mk << 1) | (x >> 31).
+template <int T>
+__device__ __forceinline__ void collect_signs(const f32x16& tile, uint32_t* mk) {
+    static_for<16>([&](auto R) {
+        mk[T >> 1] = __builtin_amdgcn_alignbit(mk[T >> 1], __float_as_uint(tile[decltype(R)::value]), 31);
+    });
+}
+
 // buffer descriptor over the 32 rows (LD floats each) a wave writes of a row-major matrix
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(float* first_row, int ld) {
     return __builtin_amdgcn_make_buffer_rsrc(first_row, 0, 32 * ld * 4, 0x00020000);

@@ -115,15 +115,6 @@ struct LayerSide {
 // (as plain loads each one was followed by `lgkmcnt(0)`: sixteen exposed round trips per tile).
 // Every row of the p_pad-row slab is written -- padding rows repeat the last point -- because the
 // weight-gradient GEMMs contract over all p_pad rows (their deltas are zero, but 0 x garbage is not).
-// Sign bits of a tile's 16 pre-activations pushed into mask dword T / 2 (idn_internal.h "ReLU masks"):
-// one v_alignbit per value, (mk << 1) | (x >> 31).
-template <int T>
-__device__ __forceinline__ void collect_signs(const f32x16& tile, uint32_t* mk) {
-    static_for<16>([&](auto R) {
-        mk[T >> 1] = __builtin_amdgcn_alignbit(mk[T >> 1], __float_as_uint(tile[decltype(R)::value]), 31);
-    });
-}
-
 template <int NT, int STEPS, int LD>
 struct SaveSide {
     static constexpr bool kShadowStore = STEPS >= 8;

@@ -8,7 +8,7 @@
 // only HBM traffic per layer is the mask (the saved post-ReLU activation, read in accumulator
 // layout) and the delta itself, written row-major for the weight-gradient GEMMs (train.hip).
 // The separate GEMMs moved three P x 256 matrices per layer and sat on the HBM/MFMA ridge.
-#include "mlp_common.h"
+#include "mlp_x6.h"
 
 namespace idn {
 
@@ -52,9 +52,8 @@ __global__ void pack_f32_bwd_kernel(BwdPackDesc d, float4* out) {
     out[gid] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-int launch_pack_f32_bwd(const idn_facenerf_params& p, float* packed_bwd, hipStream_t s) {
+static void fill_bwd_desc(const idn_facenerf_params& p, BwdPackDesc& d) {
     const int C = p.dim_aud + p.dim_expr + p.dim_latent;
-    BwdPackDesc d;
     d.st[0] = {p.rgb_w, nullptr, IDN_W / 2, 0, 3, IDN_W / 2, -1};
     d.st[1] = {p.views_w[2], nullptr, IDN_W / 2, 0, IDN_W / 2, IDN_W / 2, -1};
     d.st[2] = {p.views_w[1], nullptr, IDN_W / 2, 0, IDN_W / 2, IDN_W / 2, -1};
@@ -63,6 +62,11 @@ int launch_pack_f32_bwd(const idn_facenerf_params& p, float* packed_bwd, hipStre
         BwdPackStage& S = d.st[4 + (7 - l)];
         S = {p.pts_w[l], nullptr, l == 5 ? IDN_PTS_CH + C + IDN_W : IDN_W, l == 5 ? IDN_PTS_CH + C : 0, IDN_W, IDN_W, -1};
     }
+}
+
+int launch_pack_f32_bwd(const idn_facenerf_params& p, float* packed_bwd, hipStream_t s) {
+    BwdPackDesc d;
+    fill_bwd_desc(p, d);
     const int total = kBwdStreamFrags * 64;
     hipLaunchKernelGGL(pack_f32_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d, reinterpret_cast<float4*>(packed_bwd));
     IDN_HIP_CHECK(hipGetLastError());
@@ -330,6 +334,242 @@ int launch_delta_chain(const float* packed_bwd, const float* acts, int64_t p_pad
     for (int l = 0; l < 8; ++l) a.da[l] = da[l];
     ProfScope prof(s, p_pad, IDN_PROF_DELTA_CHAIN);
     hipLaunchKernelGGL(delta_chain_kernel, dim3(grid), dim3(256), kDeltaLds, s, a);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+
+// ===========================================================================================
+// The same chain on the bf16 matrix pipe, fp32-grade: six bf16 piece products per fp32 product (mlp_x6.h; the
+// forward in mlp_bf16x6.hip, the weight-gradient GEMMs in train.hip).  A stage's input delta is held as pieces
+// (192 registers for 256 channels x 32 points), its output as the fp32 accumulator tiles; at the end of a stage
+// the accumulators are masked, written to the delta matrix (this lane's row: a quad of registers is 16 contiguous
+// bytes of it) and split into the piece registers, which the finished stage no longer needs.
+// Stream: per (tile, 16-channel k-step) a quad of fragments (p1, p2, p3, zero) = twice the fp32 stream's fragments,
+// stage by stage, so every stage keeps its ring phase.
+// ===========================================================================================
+constexpr int kBwd6StreamFrags = 2 * kBwdStreamFrags;   // 4352
+constexpr int kBwd6NumSlices = 2 * kBwdNumSlices;       // 68
+constexpr int bwd6_f0(int s) { return 2 * bwd_f0(s); }
+
+__global__ void pack_bf16x6_bwd_kernel(BwdPackDesc d, uint4* out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= kBwd6StreamFrags * 64) return;
+    const int f = gid >> 6, lane = gid & 63, part = f & 3;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    int s = -1;
+    for (int i = 0; i < kBwdStages; ++i)
+        if (f >= bwd6_f0(i) && f < bwd6_f0(i) + 2 * kBwdNT[i] * kBwdKG[i]) s = i;
+    if (s >= 0 && part < 3) {
+        const BwdPackStage& S = d.st[s];
+        const int ksn = kBwdKG[s] / 2;
+        const int rel = (f - bwd6_f0(s)) >> 2, t = rel / ksn, ks = rel - t * ksn;
+        const int n = 32 * t + (lane & 31), h = lane >> 5;
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + (j & 3) + 8 * (j >> 2) + 4 * h;   // the element order an accumulator tile splits into
+            float v = 0.f;
+            if (n < S.cols) {
+                if (k < S.rows) v = S.w[(long)k * S.ld + S.col0 + n];
+                else if (S.extra && k == S.extra_at) v = S.extra[n];
+            }
+            const unsigned u1 = __float_as_uint(v);
+            const unsigned p1 = (u1 + 0x7fffu + ((u1 >> 16) & 1u)) >> 16;   // bf16, round to nearest even (finite weights)
+            const float r1 = v - __uint_as_float(p1 << 16);
+            const unsigned u2 = __float_as_uint(r1);
+            const unsigned p2 = (u2 + 0x7fffu + ((u2 >> 16) & 1u)) >> 16;
+            const float r2 = r1 - __uint_as_float(p2 << 16);
+            const unsigned u3 = __float_as_uint(r2);
+            const unsigned p3 = (u3 + 0x7fffu + ((u3 >> 16) & 1u)) >> 16;
+            const unsigned bits = part == 0 ? p1 : (part == 1 ? p2 : p3);
+            w[j >> 1] |= bits << (16 * (j & 1));
+        }
+    }
+    out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+size_t bwd_stream_floats_x6() { return (size_t)kBwd6StreamFrags * kFragFloats; }
+
+int launch_pack_bf16x6_bwd(const idn_facenerf_params& p, float* packed_bwd, hipStream_t s) {
+    BwdPackDesc d;
+    fill_bwd_desc(p, d);
+    const int total = kBwd6StreamFrags * 64;
+    hipLaunchKernelGGL(pack_bf16x6_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d, reinterpret_cast<uint4*>(packed_bwd));
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+namespace x6 {
+
+// One stage's MFMAs: zeroed accumulators, KS k-steps of six piece products per tile (run_layer of mlp_bf16x6.hip
+// without the bias).  LAST: nothing is read ahead past this stage (the padding before the trunk / the end of the pass).
+template <int F0, int NT, int KS, bool LAST, class BGet>
+__device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, FragReader& fr, f32x4 (&pref)[3]) {
+    constexpr int NP = NT * KS;
+    static_assert(F0 % 4 == 0, "quads");
+    static_for<NT>([&](auto T) { static_for<16>([&](auto R) { O[decltype(T)::value][decltype(R)::value] = 0.0f; }); });
+    if constexpr (F0 % kSliceFrags == 0) {
+        ws.open_slice();
+        static_for<3>([&](auto Q) { pref[decltype(Q)::value] = fr.template issue<F0 + decltype(Q)::value>(); });
+        retire3<0>(pref);
+    }
+    f32x4 a[3] = {pref[0], pref[1], pref[2]};
+    static_for<NP>([&](auto PI) {
+        constexpr int pi = decltype(PI)::value;
+        constexpr int t = pi / KS, s = pi % KS;
+        constexpr int f = F0 + 4 * pi;
+        constexpr bool next_crosses = ((f + 4) % kSliceFrags == 0);
+        constexpr bool has_next = !(LAST && pi + 1 == NP);
+        f32x4 n[3] = {a[0], a[1], a[2]};
+        if constexpr (!next_crosses && has_next) {
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
+            if constexpr (pi > 0) retire3<3>(a);   // (step 0's arrived retired)
+        } else {
+            if constexpr (pi > 0) retire3<0>(a);
+        }
+        ws.template step_piece<f>();
+        ws.template step_piece<f + 2>();
+        const f32x4 b1 = bget(ic<0>{}, ic<s>{}), b2 = bget(ic<1>{}, ic<s>{}), b3 = bget(ic<2>{}, ic<s>{});
+        O[t] = mfma_bf(a[0], b1, O[t]);
+        O[t] = mfma_bf(a[0], b2, O[t]);
+        O[t] = mfma_bf(a[1], b1, O[t]);
+        O[t] = mfma_bf(a[1], b2, O[t]);
+        O[t] = mfma_bf(a[0], b3, O[t]);
+        O[t] = mfma_bf(a[2], b1, O[t]);
+        if constexpr (next_crosses && pi + 1 < NP) {
+            ws.open_slice();
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
+        }
+        a[0] = n[0];
+        a[1] = n[1];
+        a[2] = n[2];
+    });
+    if constexpr (!LAST && (F0 + 4 * NP) % kSliceFrags != 0) retire3<0>(a);   // hand over retired fragments
+    pref[0] = a[0];
+    pref[1] = a[1];
+    pref[2] = a[2];
+}
+
+constexpr int kDelta6Lds = kRingFrags * kFragBytes;
+
+__global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, h = lane >> 5;
+
+    Diag dg;
+    WStream ws;
+    ws.dg = &dg;
+    ws.init(a.wstream, kBwd6NumSlices, ring, tid, wave);
+    FragReader fr;
+    fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
+    fr.addr1 = fr.addr0 + 64 * kFragBytes;
+    const long ntiles = a.p_pad >> 7;
+    f32x4 pref[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long P = tile * 128 + wave * 32 + m;
+        // d raw of this lane's point: rgb in k-channels 0..2 (lane half 0), sigma in k-channel 128
+        const f32x4 drgb = *reinterpret_cast<const f32x4*>(a.d_rgb + P * 64);
+        const float dsig = a.dv0[P * 256 + kSigmaChannel];
+        // as pieces of one k-step: word 0 = channels (0, 1), word 1 = (2, 3) of lane half 0; everything else zero
+        f32x4 in_rgb[3], in_sig[3];
+        {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            float r[3][2], g[3];
+            split3(h ? 0.0f : drgb[0], h ? 0.0f : drgb[1], r[0][0], r[1][0], r[2][0]);
+            split3(h ? 0.0f : drgb[2], 0.0f, r[0][1], r[1][1], r[2][1]);
+            float unused0, unused1, unused2;
+            (void)unused0; (void)unused1; (void)unused2;
+            split3(h ? 0.0f : dsig, 0.0f, g[0], g[1], g[2]);
+            static_for<3>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                in_rgb[q] = z4;
+                in_rgb[q][0] = r[q][0];
+                in_rgb[q][1] = r[q][1];
+                in_sig[q] = z4;
+                in_sig[q][0] = g[q];
+            });
+        }
+
+        PTile6 Pt[8];
+        f32x16 O[8];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* mbase = reinterpret_cast<const u32x4*>(a.acts + (size_t)kActCols * a.p_pad);
+        auto mask_load = [&](int id) { return mbase[mask_index(id, a.p_pad, tile * 4 + wave, lane)]; };
+        u32x4 mask_nxt = mask_load(10);
+        auto tiles = [&](auto Q, auto S_) {
+            constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
+            return Pt[s >> 1].p[q][s & 1];
+        };
+        // one stage: MFMAs, then mask (this stage's ReLU bits, loaded a stage ahead), store the delta rows, split into pieces
+        auto stage_run = [&](auto F0c, auto NTc, auto KSc, auto LASTc, auto LDc, auto&& bget, int next_id, float* dst) {
+            constexpr int NT = decltype(NTc)::value, LD = decltype(LDc)::value;
+            const u32x4 mv = mask_nxt;
+            const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
+            if (next_id >= 0) mask_nxt = mask_load(next_id);
+            run_stage6<decltype(F0c)::value, NT, decltype(KSc)::value, decltype(LASTc)::value != 0>(O, bget, ws, fr, pref);
+            float* row = dst + P * LD + 4 * h;
+            static_for<NT>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                const uint32_t w = mk[t >> 1];
+                static_for<16>([&](auto R) {
+                    constexpr int r = decltype(R)::value, i = 16 * (t & 1) + r;
+                    const int off = (int)(w << i) >> 31;   // all ones where the unit was off (sign bit of its pre-activation)
+                    O[t][r] = __uint_as_float(__float_as_uint(O[t][r]) & ~(uint32_t)off);
+                });
+                static_for<4>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) = f32x4{O[t][4 * q], O[t][4 * q + 1], O[t][4 * q + 2], O[t][4 * q + 3]};
+                });
+                convert_tile<false>(O[t], Pt[t]);
+            });
+        };
+        // 0: rgb_linear^T : d rgb (3) -> delta of views_linears.2, masked by its output v3
+        stage_run(ic<bwd6_f0(0)>{}, ic<4>{}, ic<1>{}, ic<0>{}, ic<128>{}, [&](auto Q, auto) { return in_rgb[decltype(Q)::value]; }, 9, a.dv2);
+        // 1: views_linears.2^T -> delta of views_linears.1 (mask v2);  2: views_linears.1^T -> views_linears.0 (mask v1)
+        stage_run(ic<bwd6_f0(1)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<128>{}, tiles, 8, a.dv1);
+        stage_run(ic<bwd6_f0(2)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<256>{}, tiles, 7, a.dv0);
+        // 3: views_linears.0[:, :256]^T + alpha_linear^T (d sigma as k-channel 128) -> delta of pts_linears.7 (mask a8)
+        stage_run(ic<bwd6_f0(3)>{}, ic<8>{}, ic<9>{}, ic<1>{}, ic<256>{},
+                  [&](auto Q, auto S_) {
+                      constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
+                      if constexpr (s < 8) return Pt[s >> 1].p[q][s & 1];
+                      else return in_sig[q];
+                  },
+                  6, a.da[7]);
+        finish_pass<2 * kBwdHeadFrags, 2 * kBwdTrunk0>(ws);   // walk the padding up to the trunk stages
+        // 4..9: pts_linears.7 .. .2 ^T, one code instance (a trunk stage is four ring lengths); then pts_linears.1^T
+#pragma unroll 1
+        for (int L = 7; L >= 2; --L)
+            stage_run(ic<bwd6_f0(4)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<256>{}, tiles, L - 2, a.da[L - 1]);   // masks a_L: id L - 1
+        stage_run(ic<bwd6_f0(10)>{}, ic<8>{}, ic<16>{}, ic<1>{}, ic<256>{}, tiles, -1, a.da[0]);            // masks a1: id 0
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+}
+
+}  // namespace x6
+
+int launch_delta_chain_x6(const float* packed_bwd, const float* acts, int64_t p_pad, const float* d_rgb, float* dv0,
+                          float* dv2, float* dv1, float* const da[8], hipStream_t s) {
+    if (p_pad <= 0) return IDN_OK;
+    if (p_pad % 128) return fail(IDN_EINVAL, "delta chain: p_pad %lld is not a multiple of 128", (long long)p_pad);
+    static LaunchSetup setup;
+    int num_cu = 0;
+    if (int e = setup.get([]() -> int {
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::delta_chain_x6_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, x6::kDelta6Lds));
+            return IDN_OK;
+        }, &num_cu))
+        return e;
+    const int64_t ntiles = p_pad / 128;
+    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
+    DeltaArgs a{packed_bwd, acts, (long)p_pad, d_rgb, dv0, dv2, dv1, {}};
+    for (int l = 0; l < 8; ++l) a.da[l] = da[l];
+    ProfScope prof(s, p_pad, IDN_PROF_DELTA_CHAIN);
+    hipLaunchKernelGGL(x6::delta_chain_x6_kernel, dim3(grid), dim3(256), x6::kDelta6Lds, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

@@ -104,6 +104,9 @@ __device__ __forceinline__ void tn_static_for(F&& f) {
 // row offset (half the issue cost of the per-lane-pointer form), and they have a whole chunk to land: the
 // GEMM reads 2 KiB per point and layer for 131 kFLOP, i.e. it needs 2.5 TB/s of HBM at the MFMA peak.
 constexpr int kTnRows = 16, kTnBufs = 3;
+#ifndef IDN_DELTA_X6
+#define IDN_DELTA_X6 1  // the backward delta chain as six bf16 piece products per fp32 product (delta_chain_x6_kernel); 0: fp32 MFMA
+#endif
 #ifndef IDN_DW_X6
 #define IDN_DW_X6 1    // 256 x 256 dW GEMMs as six bf16 piece products (gemm_tn_x6_kernel); 0: the fp32-MFMA kernel
 #endif
@@ -811,7 +814,7 @@ static BwdWs carve_bwd(char* base, int64_t p_pad) {
     w.dRGB = take((size_t)p_pad * 64);
     w.part = take((size_t)kMaxSplits * kPartFloatsPerSplit);   // one slab per GEMM of the pass: they are all reduced at its end
     w.cpart = take((size_t)kColsumBlocks * 256 * kGemmsPerPass);
-    w.wbwd = take((size_t)kBwdStreamFrags * kFragFloats);               // transposed weight stream of the delta chain
+    w.wbwd = take(IDN_DELTA_X6 ? bwd_stream_floats_x6() : (size_t)kBwdStreamFrags * kFragFloats);   // transposed weight stream of the delta chain
     w.bytes = off;
     return w;
 }
@@ -1040,8 +1043,13 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
 #define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
     // All pre-activation deltas in one fused pass over the points (mlp_f32_bwd.hip): dV[0] = delta of
     // views_linears.2, dV[1] = views_linears.1, dV0[:, :128] = views_linears.0 (col 128 = d sigma), dA[l] = pts_linears.l
+#if IDN_DELTA_X6
+    TRY(launch_pack_bf16x6_bwd(p, w.wbwd, s));
+    TRY(launch_delta_chain_x6(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
+#else
     TRY(launch_pack_f32_bwd(p, w.wbwd, s));
     TRY(launch_delta_chain(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
+#endif
     // weight and bias gradients: dW_l = delta_l^T a_{l-1} (contraction over the points), db_l = column sums
     ReduceQueue q(w.part, w.cpart);
     TRY(run_tn(q, w.dRGB, 64, 64, v_l(3), 128, 128, Pp, gr.rgb_w, 128, 3, 128, s, gr.rgb_b, 3));
