@@ -119,7 +119,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
     Diag dg;
     WStream ws;
     ws.dg = &dg;
+#ifdef IDN_TIMING_STREAM_WRAP   // timing-only (wrong results): the stream wraps after this many slices -- does the 4.5 MiB stream miss L2?
+    ws.init(a.wstream, IDN_TIMING_STREAM_WRAP, ring, tid, wave);
+#else
     ws.init(a.wstream, kX6NumSlices, ring, tid, wave);
+#endif
     PeLane pln;
     pln.init(h);
 
@@ -186,7 +190,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
         f32x16 O[8];
         uint32_t mk[4] = {0u, 0u, 0u, 0u};   // SAVE: the current layer's ReLU mask bits
         // SAVE: record layer `idx` of the activation slab (LD floats per row) and its mask words (layer id idx - kActA1)
-        auto finish_layer = [&](auto NTc, auto LDc, int idx) {
+        // (always_inline: left to its heuristics hipcc made the inference variant's eight identical calls a real function,
+        //  with the 320 registers of O and Pt passed through scratch memory: 11x slower)
+        auto finish_layer = [&](auto NTc, auto LDc, int idx) __attribute__((always_inline)) {
             constexpr int NT = decltype(NTc)::value, LD = decltype(LDc)::value;
             if constexpr (SAVE) {
                 convert_layer<NT, true>(O, Pt, a.acts + (long)act_off(idx) * a.p_pad + P * LD + 4 * h, mk);

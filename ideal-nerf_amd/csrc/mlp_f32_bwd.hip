@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
             return Pt[s >> 1].p[q][s & 1];
         };
         // one stage: MFMAs, then mask (this stage's ReLU bits, loaded a stage ahead), store the delta rows, split into pieces
-        auto stage_run = [&](auto F0c, auto NTc, auto KSc, auto LASTc, auto LDc, auto&& bget, int next_id, float* dst) {
+        auto stage_run = [&](auto F0c, auto NTc, auto KSc, auto LASTc, auto LDc, auto&& bget, int next_id, float* dst) __attribute__((always_inline)) {
             constexpr int NT = decltype(NTc)::value, LD = decltype(LDc)::value;
             const u32x4 mv = mask_nxt;
             const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};

@@ -256,12 +256,16 @@ def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
         return str(out)
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
-        files = list(ex.map(compile_s, ["mlp_f32", "mlp_bf16x3", "mlp_f32_bwd", "train"]))
+        files = list(ex.map(compile_s, ["mlp_f32", "mlp_bf16x3", "mlp_bf16x6", "mlp_f32_bwd", "train"]))
     for f in files:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), f, ""],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
         assert "0 suspicious touches" in r.stdout
+        # every device function is inlined into its kernel: a real call passes the register-resident layer state through
+        # scratch memory (a generic lambda called eight times was once left out of line: 11x slower, same results)
+        isa = open(f).read()
+        assert "s_swappc_b64" not in isa and "s_setpc_b64" not in isa, f
     # the auditor's second check (inline-asm VALU reading a VGPR an MFMA has just written: the
     # plain-bf16 kernel keeps its accumulators in VGPRs) must fire on a known-bad sequence
     bad = tmp_path / "bad.s"
