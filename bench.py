@@ -204,10 +204,12 @@ def init_ranks(need_gpu=True):
     backend = None
     if world > 1:
         backend = os.environ.get("IDN_DIST_BACKEND", "nccl")
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("IDN_DIST_TIMEOUT_S", "300")))   # a rank that never shows up is an error, not a 30-minute wait
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
         assert dist.get_world_size() == world
     return world, rank, dev, backend
 
@@ -280,14 +282,17 @@ def bench_train(args):
     kinds = profile_kinds(lib)
     samples = len(sel) * 256 * args.steps
     # the MFMA kernel families of a step; forward and delta chain count the points they were launched on, the dW
-    # GEMMs the step's points (one launch per layer contracts over all of them).  The seven 256 x 256 dW GEMMs run
-    # on the bf16 pipe as six piece products per fp32 product (fp32-grade result): priced against bf16 peak / 6.
-    fl = {"mlp_fwd_save": samples * FLOP_PER_SAMPLE, "delta_chain": samples * FLOP_PER_SAMPLE_DX,
-          "dw_gemm_x6": samples * FLOP_PER_SAMPLE_DW_X6, "dw_gemm": samples * (FLOP_PER_SAMPLE - FLOP_PER_SAMPLE_DW_X6)}
-    peaks = {"mlp_fwd_save": PEAK_F32_MFMA_TFLOPS, "delta_chain": PEAK_F32_MFMA_TFLOPS, "dw_gemm": PEAK_F32_MFMA_TFLOPS,
-             "dw_gemm_x6": PEAK_BF16_MFMA_TFLOPS / 6.0}
-    if kinds["dw_gemm_x6"][1] == 0:      # a build with -DIDN_DW_X6=0: every dW GEMM on the fp32 pipe
-        fl["dw_gemm"] += fl.pop("dw_gemm_x6")
+    # GEMMs the step's points (one launch per layer contracts over all of them).  Families on the bf16 pipe compute
+    # six piece products per fp32 product (fp32-grade result): priced against bf16 peak / 6; the others against fp32 MFMA.
+    X6 = PEAK_BF16_MFMA_TFLOPS / 6.0
+    fl, peaks = {}, {}
+    for k, flop, pk in (("mlp_fwd_save", FLOP_PER_SAMPLE, PEAK_F32_MFMA_TFLOPS), ("mlp_fwd_save_x6", FLOP_PER_SAMPLE, X6),
+                        ("delta_chain", FLOP_PER_SAMPLE_DX, PEAK_F32_MFMA_TFLOPS), ("delta_chain_x6", FLOP_PER_SAMPLE_DX, X6),
+                        ("dw_gemm_x6", FLOP_PER_SAMPLE_DW_X6, X6), ("dw_gemm", FLOP_PER_SAMPLE - FLOP_PER_SAMPLE_DW_X6, PEAK_F32_MFMA_TFLOPS)):
+        if kinds[k][1] > 0:      # the families this build / IDN_TRAIN_PRECISION actually launched
+            fl[k], peaks[k] = samples * flop, pk
+    if "dw_gemm_x6" not in fl:   # a build with -DIDN_DW_X6=0: every dW GEMM on the fp32 pipe
+        fl["dw_gemm"] = samples * FLOP_PER_SAMPLE
     split = {k: {"ms_per_step": kinds[k][0] / args.steps, "launches_per_step": kinds[k][1] / args.steps,
                  "algorithmic_tflops": fl[k] / (kinds[k][0] * 1e-3) / 1e12 if kinds[k][0] > 0 else None,
                  "peak_tflops": peaks[k],
@@ -301,13 +306,15 @@ def bench_train(args):
                       "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f32", "data": "synthetic",
-                      "dw_arithmetic": "dW of the seven 256x256 layers: each fp32 operand as the exact sum of three bf16 pieces, six "
-                                       "piece products per product on the bf16 MFMA pipe, fp32 accumulate (error ~2^-23 per product, "
-                                       "as an fp32 fma chain; gradient parity tests unchanged); everything else fp32 MFMA / VALU",
+                      "arithmetic": "families named `_x6`: every fp32 operand as the exact sum of three bf16 pieces, six piece products per "
+                                    "product on the bf16 MFMA pipe, fp32 accumulate (error <= 2^-23 per product, as an fp32 fma chain; "
+                                    "gradient parity tests unchanged); the others fp32 MFMA / VALU.  IDN_TRAIN_PRECISION=f32 and a build with "
+                                    "-DIDN_DELTA_X6=0 -DIDN_DW_X6=0 put everything on the fp32 pipe",
                       "config": {"workload": "BASELINE configs[2]: May HeadNeRF train step, N_rand=3072 mouth_rays=512 "
                                              "dim_aud=64 dim_expr=76, perturb=1"},
-                      "roofline": {"bound": "mfma", "kernel": "idn::mlp_f32_kernel<kModeRays, SAVE> + idn::delta_chain_kernel (fp32 MFMA) + "
-                                                             "idn::gemm_tn_x6_kernel (bf16 MFMA, 6 piece products) + idn::gemm_tn_kernel (fp32 MFMA)",
+                      "roofline": {"bound": "mfma", "kernel": "the step's MFMA kernel families (see `kernels`): forward with saved activations, delta chain, "
+                                                             "256x256 dW GEMMs -- `_x6` = bf16 MFMA, six piece products per fp32 product -- and the "
+                                                             "64/128-wide dW GEMMs (fp32 MFMA)",
                                    "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                    "frac": ach / peak if ach else None, "traffic": None,
                                    "flop_per_sample": FLOP_PER_SAMPLE_STEP, "kernels": split,

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("IDN_LIB") or os.path.join(HERE, "libidealnerf.so")
 
 IDN_PREC_F32, IDN_PREC_BF16X3, IDN_PREC_BF16, IDN_PREC_FP16X3, IDN_PREC_BF16X6 = 0, 1, 2, 3, 4
 RAY_FLOATS = 11
-PROF_KINDS = ("mlp_fwd", "mlp_fwd_save", "delta_chain", "dw_gemm", "dw_gemm_x6")   # IDN_PROF_* of include/idealnerf.h
+PROF_KINDS = ("mlp_fwd", "mlp_fwd_save", "delta_chain", "dw_gemm", "dw_gemm_x6", "mlp_fwd_save_x6", "delta_chain_x6")   # IDN_PROF_* of include/idealnerf.h
 
 fp = C.c_void_p  # device pointers travel as integers
 

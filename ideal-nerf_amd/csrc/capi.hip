@@ -313,9 +313,9 @@ int idealnerf_profile_end(double* total_ms, int64_t* launches, int64_t* points) 
     int64_t n[IDN_PROF_KINDS], pts[IDN_PROF_KINDS];
     if (int e = idealnerf_profile_end_kinds(ms, n, pts)) return e;
     // the forward MLP launches, with or without saved activations
-    if (total_ms) *total_ms = ms[IDN_PROF_MLP_FWD] + ms[IDN_PROF_MLP_FWD_SAVE];
-    if (launches) *launches = n[IDN_PROF_MLP_FWD] + n[IDN_PROF_MLP_FWD_SAVE];
-    if (points) *points = pts[IDN_PROF_MLP_FWD] + pts[IDN_PROF_MLP_FWD_SAVE];
+    if (total_ms) *total_ms = ms[IDN_PROF_MLP_FWD] + ms[IDN_PROF_MLP_FWD_SAVE] + ms[IDN_PROF_MLP_FWD_SAVE_X6];
+    if (launches) *launches = n[IDN_PROF_MLP_FWD] + n[IDN_PROF_MLP_FWD_SAVE] + n[IDN_PROF_MLP_FWD_SAVE_X6];
+    if (points) *points = pts[IDN_PROF_MLP_FWD] + pts[IDN_PROF_MLP_FWD_SAVE] + pts[IDN_PROF_MLP_FWD_SAVE_X6];
     return IDN_OK;
 }
 

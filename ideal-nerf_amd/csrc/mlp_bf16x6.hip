@@ -290,7 +290,7 @@ int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, 
     const int64_t ntiles = (n_points + 127) / 128;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, acts, (long)p_pad};
-    ProfScope prof(s, n_points, acts ? IDN_PROF_MLP_FWD_SAVE : IDN_PROF_MLP_FWD);
+    ProfScope prof(s, n_points, acts ? IDN_PROF_MLP_FWD_SAVE_X6 : IDN_PROF_MLP_FWD);
     if (x)
         hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeX, false>), dim3(grid), dim3(256), kMlpLds, s, a);
     else if (pts)

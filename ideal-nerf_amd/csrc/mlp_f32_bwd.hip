@@ -568,7 +568,7 @@ int launch_delta_chain_x6(const float* packed_bwd, const float* acts, int64_t p_
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     DeltaArgs a{packed_bwd, acts, (long)p_pad, d_rgb, dv0, dv2, dv1, {}};
     for (int l = 0; l < 8; ++l) a.da[l] = da[l];
-    ProfScope prof(s, p_pad, IDN_PROF_DELTA_CHAIN);
+    ProfScope prof(s, p_pad, IDN_PROF_DELTA_CHAIN_X6);
     hipLaunchKernelGGL(x6::delta_chain_x6_kernel, dim3(grid), dim3(256), x6::kDelta6Lds, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;

@@ -6,6 +6,8 @@ load unchanged.  The arithmetic runs in libidealnerf.so: the parameters are re-l
 the MFMA weight stream once per update, the per-frame conditioning vectors are folded
 into biases once per call, and the per-point contraction is one fused HIP kernel.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -14,11 +16,12 @@ from .._lib import IDN_PREC_BF16, IDN_PREC_BF16X3, IDN_PREC_BF16X6, IDN_PREC_F32
 
 PRECISIONS = {"f32": IDN_PREC_F32, "bf16x3": IDN_PREC_BF16X3, "bf16": IDN_PREC_BF16, "fp16x3": IDN_PREC_FP16X3,
               "bf16x6": IDN_PREC_BF16X6}
-_default_precision = ["f32"]
+_default_precision = [os.environ.get("IDN_DEFAULT_PRECISION", "f32")]   # modules created from here on (set_default_precision)
 
 
 def set_render_precision(network, mode: str):
-    """Arithmetic of a Network's coarse / fine pair: "f32", "bf16x3", "bf16", or "mixed" = exact fp32 for
+    """Arithmetic of a Network's coarse / fine pair: "f32" (fp32 MFMA), "bf16x6" (six bf16 piece products per fp32
+    product: the fp32 kernel's parity at 1.7x its speed), "fp16x3", "bf16x3", "bf16", or "mixed" = exact fp32 for
     the coarse network (its output drives the importance sampling) and bf16x3 for the fine one (3/4 of
     the samples): about twice the fp32 speed inside the 1e-4 RGB budget, also on sharp scenes."""
     pairs = [(getattr(network, c, None), getattr(network, f, None))
@@ -44,7 +47,8 @@ def invalidate_packed(module):
 
 def set_default_precision(name: str):
     """Arithmetic of the MLP contraction for modules created afterwards: "f32" (exact fp32
-    MFMA), "bf16x3" (three bf16 MFMAs per product, ~1.5e-5 relative on the output) or "bf16"
+    MFMA), "bf16x6" (weights and activations as three bf16 pieces, six MFMAs per product: fp32-grade),
+    "bf16x3" (three bf16 MFMAs per product, ~1.5e-5 relative on the output), "fp16x3" or "bf16"
     (plain bf16, ~1e-2: PSNR-judged rendering only, BASELINE config 5)."""
     if name not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")

@@ -337,7 +337,9 @@ int idealnerf_profile_end(double* total_ms, int64_t* launches, int64_t* points);
 #define IDN_PROF_DELTA_CHAIN 2  /* fused backward delta chain */
 #define IDN_PROF_DW_GEMM 3      /* dW = delta^T . activation GEMMs (+ bias column sums) on the fp32 matrix pipe */
 #define IDN_PROF_DW_GEMM_X6 4   /* the 256 x 256 dW GEMMs: six bf16 piece products per fp32 product, fp32 accumulate */
-#define IDN_PROF_KINDS 5
+#define IDN_PROF_MLP_FWD_SAVE_X6 5 /* training forward as six bf16 piece products per fp32 product (IDN_PREC_BF16X6) */
+#define IDN_PROF_DELTA_CHAIN_X6 6  /* backward delta chain, the same arithmetic */
+#define IDN_PROF_KINDS 7
 int idealnerf_profile_end_kinds(double* total_ms, int64_t* launches, int64_t* points);
 
 #ifdef __cplusplus
