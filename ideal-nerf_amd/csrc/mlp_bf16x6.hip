@@ -28,15 +28,19 @@ constexpr int f0(int l) { return 2 * layer_f0(l); }   // quads: 4 fragments per 
 // piece q of k-step s of the layer's input.  The first fragments arrive in `pref` (issued by the layer before, or
 // here when the layer starts on a slice boundary) and leave in it for the next layer, VALID (retired): the
 // conversion between two layers is long, and a register with a read in flight must not be moved or spilled.
-template <int F0, int NT, int KS, class BGet, class Hook = NoHook>
+struct NoTileSide {
+    template <int T, int S>
+    __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {}
+};
+template <int F0, int NT, int KS, int OPEN_YOUNGER = 0, class BGet, class Side = NoTileSide, class Hook = NoHook>
 __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGet&& bget, WStream& ws, FragReader& fr,
-                                          f32x4 (&pref)[3], Hook&& after_open = NoHook{}) {
+                                          f32x4 (&pref)[3], Side&& side = NoTileSide{}, Hook&& after_open = NoHook{}) {
     constexpr int NP = NT * KS;
     constexpr bool LAST = (F0 + 4 * NP == kX6UsedFrags);
     static_assert(F0 % 4 == 0 && KS >= 4, "quads; the next tile's bias rides on the first four k-steps");
     bias_tile(O[0], bias_half);
     if constexpr (F0 % kSliceFrags == 0) {
-        ws.open_slice();
+        ws.template open_slice<OPEN_YOUNGER>();   // (training: the row stores of the layer before stay in flight)
         after_open();
         static_for<3>([&](auto Q) { pref[decltype(Q)::value] = fr.template issue<F0 + decltype(Q)::value>(); });
         retire3<0>(pref);
@@ -65,6 +69,7 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
         O[t] = mfma_bf(a[1], b1, O[t]);   // w2 a1
         if constexpr (t + 1 < NT && s < 4) bias_quad<s>(O[t + 1], bias_half + 32 * (t + 1));   // the next tile starts from its bias
         O[t] = mfma_bf(a[1], b2, O[t]);   // w2 a2
+        side(ic<t>{}, ic<s>{});           // training: the finished tile t - 1 is recorded in this tile's shadow
         O[t] = mfma_bf(a[0], b3, O[t]);   // w1 a3
         O[t] = mfma_bf(a[2], b1, O[t]);   // w3 a1
         if constexpr (next_crosses && pi + 1 < NP) {
@@ -82,24 +87,45 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
     pref[2] = a[2];
 }
 
-// End of a layer: the NT accumulator tiles are ReLU'd and split into the piece registers (the next layer's input).
-// Training (SAVE): the sign bits of the pre-activations go into the layer's mask words and the post-ReLU values into
-// this lane's row of the layer's activation matrix (`row` = its first float + 4 h; register 4 q + j of tile t is
-// channel 32 t + 8 q + 4 h + j, so a quad of registers is 16 contiguous bytes of the row).
-template <int NT, bool SAVE>
-__device__ __forceinline__ void convert_layer(const f32x16* O, PTile6* P, float* row = nullptr, uint32_t* mk = nullptr) {
-    static_for<NT>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        if constexpr (SAVE) {
-            collect_signs<t>(O[t], mk);
-            static_for<4>([&](auto Q) {
-                constexpr int q = decltype(Q)::value;
-                *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) =
-                    f32x4{relu1(O[t][4 * q]), relu1(O[t][4 * q + 1]), relu1(O[t][4 * q + 2]), relu1(O[t][4 * q + 3])};
-            });
-        }
-        convert_tile<true>(O[t], P[t]);
-    });
+// Training: a layer's tiles are RECORDED when the layer is complete, all of them BEFORE any is converted -- the sign
+// bits of the 16 pre-activations into the layer's mask word, the ReLU applied in place, the 16 values into this lane's
+// row of the layer's activation matrix (`row` = its first float + 4 h; register 4 q + j of tile t is channel
+// 32 t + 8 q + 4 h + j, so a quad of registers is 16 contiguous bytes of the row).  On gfx9 stores count in vmcnt, and
+// the next slice barrier's vmcnt(0) waits for them: issued first, they complete behind the conversion's ~3 000 cycles of
+// vector work.  (Recording tile t - 1 in the MFMA shadow of tile t was tried: every slice barrier of the layer then
+// waits for a store issued half a slice earlier -- forward 4.96 -> 5.36 ms, delta chain 4.49 -> 5.34.)
+struct RecordSide {
+    f32x16* O;
+    uint32_t* mk;
+    float* row;
+    template <int T>
+    __device__ __forceinline__ void signs_relu(ic<T>) const {
+        collect_signs<T>(O[T], mk);
+        relu_regs<0, 16>(O[T]);
+    }
+    template <int T, int Q0>
+    __device__ __forceinline__ void store2(ic<T>, ic<Q0>) const {
+#ifdef IDN_TIMING_NO_ROW_STORES   // timing-only experiment (wrong results): what do the row stores cost?
+        return;
+#endif
+        static_for<2>([&](auto I) {
+            constexpr int q = Q0 + decltype(I)::value;
+            *reinterpret_cast<f32x4*>(row + 32 * T + 8 * q) = f32x4{O[T][4 * q], O[T][4 * q + 1], O[T][4 * q + 2], O[T][4 * q + 3]};
+        });
+    }
+    template <int T>
+    __device__ __forceinline__ void whole(ic<T>) const {
+        signs_relu(ic<T>{});
+        store2(ic<T>{}, ic<0>{});
+        store2(ic<T>{}, ic<2>{});
+    }
+};
+
+// End of a layer: the NT accumulator tiles are split into the piece registers (the next layer's input), ReLU'd on
+// the way unless the training path has already done that in place.
+template <int NT, bool RELU>
+__device__ __forceinline__ void convert_layer(const f32x16* O, PTile6* P) {
+    static_for<NT>([&](auto T) { convert_tile<RELU>(O[decltype(T)::value], P[decltype(T)::value]); });
 }
 
 template <int MODE, bool SAVE>
@@ -188,66 +214,78 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
 
         PTile6 Pt[8];
         f32x16 O[8];
-        uint32_t mk[4] = {0u, 0u, 0u, 0u};   // SAVE: the current layer's ReLU mask bits
-        // SAVE: record layer `idx` of the activation slab (LD floats per row) and its mask words (layer id idx - kActA1)
-        // (always_inline: left to its heuristics hipcc made the inference variant's eight identical calls a real function,
-        //  with the 320 registers of O and Pt passed through scratch memory: 11x slower)
-        auto finish_layer = [&](auto NTc, auto LDc, int idx) __attribute__((always_inline)) {
-            constexpr int NT = decltype(NTc)::value, LD = decltype(LDc)::value;
-            if constexpr (SAVE) {
-                convert_layer<NT, true>(O, Pt, a.acts + (long)act_off(idx) * a.p_pad + P * LD + 4 * h, mk);
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(idx - kActA1, a.p_pad, tile * 4 + wave, lane);
-                *mp = u32x4{mk[0], mk[1], mk[2], mk[3]};
-            } else {
-                convert_layer<NT, false>(O, Pt);
-            }
-        };
         auto tiles = [&](auto Q, auto S_) {
             constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
             return Pt[s >> 1].p[q][s & 1];
         };
+        uint32_t mk[4] = {0u, 0u, 0u, 0u};   // SAVE: the current layer's ReLU mask bits
+        // One hidden layer: MFMAs (training: with the finished tiles recorded in their shadow), then the accumulators
+        // become the next layer's input pieces.  `idx` = the layer's matrix in the activation slab (LD floats per row).
+        // (always_inline: left to its heuristics hipcc made the inference variant's eight identical calls a real function,
+        //  with the 320 registers of O and Pt passed through scratch memory: 11x slower)
+        // A trunk layer after the first opens its first slice behind the 8 x 4 row stores (+ 1 mask store) of the layer before
+        // it, all younger than this wave's pieces of that slice.  (Never more than were issued: the count must not reach
+        // back into the pieces.)
+        constexpr int kRecordOps = 8 * 4;
+        auto layer = [&](auto F0c, auto NTc, auto KSc, auto LDc, const float* bias_l, auto&& bget, int idx, auto&& hook) __attribute__((always_inline)) {
+            constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KS = decltype(KSc)::value, LD = decltype(LDc)::value;
+            if constexpr (SAVE) {
+                const RecordSide rec{O, mk, a.acts + (long)act_off(idx) * a.p_pad + P * LD + 4 * h};
+                run_layer<F0, NT, KS, (F0 > 0 ? kRecordOps : 0)>(O, bias_l, bget, ws, fr, pref, NoTileSide{}, hook);
+                static_for<NT>([&](auto T) { rec.whole(T); });
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(idx - kActA1, a.p_pad, tile * 4 + wave, lane);
+                *mp = u32x4{mk[0], mk[1], mk[2], mk[3]};
+                convert_layer<NT, false>(O, Pt);
+            } else {
+                run_layer<F0, NT, KS>(O, bias_l, bget, ws, fr, pref, NoTileSide{}, hook);
+                convert_layer<NT, true>(O, Pt);
+            }
+        };
         // ---- pts_linears.0 : PE(64) -> 256
-        run_layer<f0(0), 8, 4>(O, bias_h + bias_off(0), [&](auto Q, auto S_) { return pe_p[decltype(Q)::value][decltype(S_)::value]; }, ws, fr, pref);
-        finish_layer(ic<8>{}, ic<256>{}, kActA1 + 0);
+        layer(ic<f0(0)>{}, ic<8>{}, ic<4>{}, ic<256>{}, bias_h + bias_off(0),
+              [&](auto Q, auto S_) { return pe_p[decltype(Q)::value][decltype(S_)::value]; }, kActA1 + 0, NoHook{});
         // ---- pts_linears.1..4 : one code instance (a 256 x 256 layer is four ring lengths of the stream)
 #pragma unroll 1
-        for (int l = 1; l <= 4; ++l) {
-            run_layer<f0(1), 8, 16>(O, bias_h + l * 256, tiles, ws, fr, pref);
-            finish_layer(ic<8>{}, ic<256>{}, kActA1 + l);
-        }
+        for (int l = 1; l <= 4; ++l) layer(ic<f0(1)>{}, ic<8>{}, ic<16>{}, ic<256>{}, bias_h + l * 256, tiles, kActA1 + l, NoHook{});
         // ---- pts_linears.5 : [PE(64) | 256] -> 256
-        run_layer<f0(5), 8, 20>(
-            O, bias_h + bias_off(5),
-            [&](auto Q, auto S_) {
-                constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
-                if constexpr (s < 4) return pe_p[q][s];
-                else return Pt[(s - 4) >> 1].p[q][(s - 4) & 1];
-            },
-            ws, fr, pref, [&]() { load_point<MODE>(a, tile + gridDim.x, wave, m, nxt); });
-        finish_layer(ic<8>{}, ic<256>{}, kActA1 + 5);
+        layer(ic<f0(5)>{}, ic<8>{}, ic<20>{}, ic<256>{}, bias_h + bias_off(5),
+              [&](auto Q, auto S_) {
+                  constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
+                  if constexpr (s < 4) return pe_p[q][s];
+                  else return Pt[(s - 4) >> 1].p[q][(s - 4) & 1];
+              },
+              kActA1 + 5, [&]() { load_point<MODE>(a, tile + gridDim.x, wave, m, nxt); });
         // ---- pts_linears.6, .7
-        run_layer<f0(6), 8, 16>(O, bias_h + bias_off(6), tiles, ws, fr, pref, [&]() { touch_point(nxt); });
-        finish_layer(ic<8>{}, ic<256>{}, kActA1 + 6);
-        run_layer<f0(7), 8, 16>(O, bias_h + bias_off(7), tiles, ws, fr, pref);
-        finish_layer(ic<8>{}, ic<256>{}, kActA1 + 7);
+        layer(ic<f0(6)>{}, ic<8>{}, ic<16>{}, ic<256>{}, bias_h + bias_off(6), tiles, kActA1 + 6, [&]() { touch_point(nxt); });
+        layer(ic<f0(7)>{}, ic<8>{}, ic<16>{}, ic<256>{}, bias_h + bias_off(7), tiles, kActA1 + 7, NoHook{});
         // ---- views_linears.0 (+ alpha_linear as channel 128): [256 | dirPE(32)] -> 160.
-        //      Tiles 0..3 are hidden units; tile 4 is never converted: its row 0 is sigma.
-        run_layer<f0(8), 5, 18>(
-            O, bias_h + bias_off(8),
-            [&](auto Q, auto S_) {
+        //      Tiles 0..3 are hidden units (recorded, converted); tile 4 is neither: its row 0 is sigma.
+        float sigma;
+        {
+            auto bget8 = [&](auto Q, auto S_) {
                 constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
                 if constexpr (s < 16) return Pt[s >> 1].p[q][s & 1];
                 else return pd_p[q][s - 16];
-            },
-            ws, fr, pref);
-        const float sigma = O[4][0];  // channel 128 = tile 4, register 0, lane half 0
-        finish_layer(ic<4>{}, ic<128>{}, kActV1);
+            };
+            if constexpr (SAVE) {
+                const RecordSide rec{O, mk, a.acts + (long)act_off(kActV1) * a.p_pad + P * 128 + 4 * h};
+                run_layer<f0(8), 5, 18, kRecordOps>(O, bias_h + bias_off(8), bget8, ws, fr, pref);
+                static_for<4>([&](auto T) { rec.whole(T); });
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(kActV1 - kActA1, a.p_pad, tile * 4 + wave, lane);
+                *mp = u32x4{mk[0], mk[1], mk[2], mk[3]};
+                sigma = O[4][0];  // channel 128 = tile 4, register 0, lane half 0
+                convert_layer<4, false>(O, Pt);
+            } else {
+                run_layer<f0(8), 5, 18>(O, bias_h + bias_off(8), bget8, ws, fr, pref);
+                sigma = O[4][0];
+                convert_layer<4, true>(O, Pt);
+            }
+        }
         // ---- views_linears.1, .2 : 128 -> 128
-        run_layer<f0(9), 4, 8>(O, bias_h + bias_off(9), tiles, ws, fr, pref);
-        finish_layer(ic<4>{}, ic<128>{}, kActV1 + 1);
-        run_layer<f0(10), 4, 8>(O, bias_h + bias_off(10), tiles, ws, fr, pref);
-        finish_layer(ic<4>{}, ic<128>{}, kActV1 + 2);
+        layer(ic<f0(9)>{}, ic<4>{}, ic<8>{}, ic<128>{}, bias_h + bias_off(9), tiles, kActV1 + 1, NoHook{});
+        layer(ic<f0(10)>{}, ic<4>{}, ic<8>{}, ic<128>{}, bias_h + bias_off(10), tiles, kActV1 + 2, NoHook{});
         // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile)
         run_layer<f0(11), 1, 8>(O, bias_h + bias_off(11), tiles, ws, fr, pref);
         finish_pass<kX6UsedFrags, kX6StreamFrags>(ws);

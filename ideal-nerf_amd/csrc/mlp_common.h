@@ -117,9 +117,15 @@ struct WStreamT {
     }
     // Open the next slice: this wave's pieces of it have landed; after the barrier every wave's
     // have, and every wave is done reading the slot the next pieces will overwrite.
+    // YOUNGER: vector-memory operations this wave has issued AFTER its last piece of the slice being opened (the row
+    // stores at the end of a training layer).  vmcnt retires in issue order -- loads, LDS-DMA pieces and stores alike --
+    // so they may stay in flight: a wait for them here would park every wave behind its own burst of writes.
+    template <int YOUNGER = 0>
     __device__ __forceinline__ void open_slice() {
         DIAG_BEGIN(*dg);
-        if constexpr (kVmcntOpen == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(kVmcntOpen + YOUNGER <= 63, "vmcnt is a 6-bit field");
+        if constexpr (YOUNGER > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kVmcntOpen + YOUNGER) : "memory");
+        else if constexpr (kVmcntOpen == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if constexpr (kVmcntOpen == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();

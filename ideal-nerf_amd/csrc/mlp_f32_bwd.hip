@@ -402,13 +402,21 @@ namespace x6 {
 
 // One stage's MFMAs: zeroed accumulators, KS k-steps of six piece products per tile (run_layer of mlp_bf16x6.hip
 // without the bias).  LAST: nothing is read ahead past this stage (the padding before the trunk / the end of the pass).
-template <int F0, int NT, int KS, bool LAST, class BGet>
-__device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, FragReader& fr, f32x4 (&pref)[3]) {
+template <int F0, int NT, int KS, bool LAST, int OPEN_YOUNGER, class BGet, class Side>
+__device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, FragReader& fr, f32x4 (&pref)[3], Side&& side, bool behind_stores) {
     constexpr int NP = NT * KS;
     static_assert(F0 % 4 == 0, "quads");
     static_for<NT>([&](auto T) { static_for<16>([&](auto R) { O[decltype(T)::value][decltype(R)::value] = 0.0f; }); });
     if constexpr (F0 % kSliceFrags == 0) {
-        ws.open_slice();
+        // behind_stores (wave-uniform): the stage before this one has just issued its 8 x 4 row stores, all of them younger
+        // than this wave's pieces of the slice being opened: they stay in flight.  (Never more than were issued: the
+        // count must not reach back into the pieces.)
+        if constexpr (OPEN_YOUNGER > 0) {
+            if (behind_stores) ws.template open_slice<OPEN_YOUNGER>();
+            else ws.open_slice();
+        } else {
+            ws.open_slice();
+        }
         static_for<3>([&](auto Q) { pref[decltype(Q)::value] = fr.template issue<F0 + decltype(Q)::value>(); });
         retire3<0>(pref);
     }
@@ -433,6 +441,7 @@ __device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, 
         O[t] = mfma_bf(a[0], b2, O[t]);
         O[t] = mfma_bf(a[1], b1, O[t]);
         O[t] = mfma_bf(a[1], b2, O[t]);
+        side(ic<t>{}, ic<s>{});   // the finished tile t - 1 is masked and written out in this tile's shadow
         O[t] = mfma_bf(a[0], b3, O[t]);
         O[t] = mfma_bf(a[2], b1, O[t]);
         if constexpr (next_crosses && pi + 1 < NP) {
@@ -448,6 +457,44 @@ __device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, 
     pref[1] = a[1];
     pref[2] = a[2];
 }
+
+// The tiles of a stage, once the stage is complete and all of them BEFORE any is converted: the ReLU bits of the layer
+// it is the delta of are applied and the 16 values go to this lane's row of the delta matrix.  (Stores count in vmcnt on
+// gfx9 and the next slice barrier's vmcnt(0) waits for them: issued first, they complete behind the conversion's vector
+// work.  In the MFMA shadow of the next tile they made every slice barrier of the stage wait: 4.49 -> 5.34 ms.)
+template <int KS>
+struct MaskStoreSide {
+    f32x16* O;
+    const uint32_t* mk;   // dword k = tiles 2k, 2k+1, value i of the pair at bit 31 - i
+    float* row;           // this lane's row of the delta matrix + 4 h
+    template <int T>
+    __device__ __forceinline__ void apply(ic<T>) const {
+        const uint32_t w = mk[T >> 1];
+        static_for<16>([&](auto R) {
+            constexpr int r = decltype(R)::value, i = 16 * (T & 1) + r;
+            const int off = (int)(w << i) >> 31;   // all ones where the unit was off (sign bit of its pre-activation)
+            O[T][r] = __uint_as_float(__float_as_uint(O[T][r]) & ~(uint32_t)off);
+        });
+    }
+    template <int T, int Q0>
+    __device__ __forceinline__ void store2(ic<T>, ic<Q0>) const {
+#ifdef IDN_TIMING_NO_ROW_STORES   // timing-only experiment (wrong results): what do the row stores cost?
+        return;
+#endif
+        static_for<2>([&](auto I) {
+            constexpr int q = Q0 + decltype(I)::value;
+            *reinterpret_cast<f32x4*>(row + 32 * T + 8 * q) = f32x4{O[T][4 * q], O[T][4 * q + 1], O[T][4 * q + 2], O[T][4 * q + 3]};
+        });
+    }
+    template <int T>
+    __device__ __forceinline__ void whole(ic<T>) const {
+        apply(ic<T>{});
+        store2(ic<T>{}, ic<0>{});
+        store2(ic<T>{}, ic<2>{});
+    }
+    template <int T, int S>
+    __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {}
+};
 
 constexpr int kDelta6Lds = kRingFrags * kFragBytes;
 
@@ -504,33 +551,23 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
             return Pt[s >> 1].p[q][s & 1];
         };
         // one stage: MFMAs, then mask (this stage's ReLU bits, loaded a stage ahead), store the delta rows, split into pieces
-        auto stage_run = [&](auto F0c, auto NTc, auto KSc, auto LASTc, auto LDc, auto&& bget, int next_id, float* dst) __attribute__((always_inline)) {
+        auto stage_run = [&](auto F0c, auto NTc, auto KSc, auto LASTc, auto LDc, auto&& bget, int next_id, float* dst, bool behind_stores) __attribute__((always_inline)) {
             constexpr int NT = decltype(NTc)::value, LD = decltype(LDc)::value;
             const u32x4 mv = mask_nxt;
             const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
             if (next_id >= 0) mask_nxt = mask_load(next_id);
-            run_stage6<decltype(F0c)::value, NT, decltype(KSc)::value, decltype(LASTc)::value != 0>(O, bget, ws, fr, pref);
-            float* row = dst + P * LD + 4 * h;
-            static_for<NT>([&](auto T) {
-                constexpr int t = decltype(T)::value;
-                const uint32_t w = mk[t >> 1];
-                static_for<16>([&](auto R) {
-                    constexpr int r = decltype(R)::value, i = 16 * (t & 1) + r;
-                    const int off = (int)(w << i) >> 31;   // all ones where the unit was off (sign bit of its pre-activation)
-                    O[t][r] = __uint_as_float(__float_as_uint(O[t][r]) & ~(uint32_t)off);
-                });
-                static_for<4>([&](auto Q) {
-                    constexpr int q = decltype(Q)::value;
-                    *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) = f32x4{O[t][4 * q], O[t][4 * q + 1], O[t][4 * q + 2], O[t][4 * q + 3]};
-                });
-                convert_tile<false>(O[t], Pt[t]);
-            });
+            const MaskStoreSide<decltype(KSc)::value> side{O, mk, dst + P * LD + 4 * h};
+            // a trunk stage after the first opens its first slice behind the 8 x 4 row stores of the stage before it
+            constexpr int kYounger = decltype(F0c)::value >= bwd6_f0(4) ? 8 * 4 : 0;
+            run_stage6<decltype(F0c)::value, NT, decltype(KSc)::value, decltype(LASTc)::value != 0, kYounger>(O, bget, ws, fr, pref, side, behind_stores);
+            static_for<NT>([&](auto T) { side.whole(T); });
+            static_for<NT>([&](auto T) { convert_tile<false>(O[decltype(T)::value], Pt[decltype(T)::value]); });
         };
         // 0: rgb_linear^T : d rgb (3) -> delta of views_linears.2, masked by its output v3
-        stage_run(ic<bwd6_f0(0)>{}, ic<4>{}, ic<1>{}, ic<0>{}, ic<128>{}, [&](auto Q, auto) { return in_rgb[decltype(Q)::value]; }, 9, a.dv2);
+        stage_run(ic<bwd6_f0(0)>{}, ic<4>{}, ic<1>{}, ic<0>{}, ic<128>{}, [&](auto Q, auto) { return in_rgb[decltype(Q)::value]; }, 9, a.dv2, false);
         // 1: views_linears.2^T -> delta of views_linears.1 (mask v2);  2: views_linears.1^T -> views_linears.0 (mask v1)
-        stage_run(ic<bwd6_f0(1)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<128>{}, tiles, 8, a.dv1);
-        stage_run(ic<bwd6_f0(2)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<256>{}, tiles, 7, a.dv0);
+        stage_run(ic<bwd6_f0(1)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<128>{}, tiles, 8, a.dv1, false);
+        stage_run(ic<bwd6_f0(2)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<256>{}, tiles, 7, a.dv0, false);
         // 3: views_linears.0[:, :256]^T + alpha_linear^T (d sigma as k-channel 128) -> delta of pts_linears.7 (mask a8)
         stage_run(ic<bwd6_f0(3)>{}, ic<8>{}, ic<9>{}, ic<1>{}, ic<256>{},
                   [&](auto Q, auto S_) {
@@ -538,13 +575,13 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
                       if constexpr (s < 8) return Pt[s >> 1].p[q][s & 1];
                       else return in_sig[q];
                   },
-                  6, a.da[7]);
+                  6, a.da[7], false);
         finish_pass<2 * kBwdHeadFrags, 2 * kBwdTrunk0>(ws);   // walk the padding up to the trunk stages
         // 4..9: pts_linears.7 .. .2 ^T, one code instance (a trunk stage is four ring lengths); then pts_linears.1^T
 #pragma unroll 1
         for (int L = 7; L >= 2; --L)
-            stage_run(ic<bwd6_f0(4)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<256>{}, tiles, L - 2, a.da[L - 1]);   // masks a_L: id L - 1
-        stage_run(ic<bwd6_f0(10)>{}, ic<8>{}, ic<16>{}, ic<1>{}, ic<256>{}, tiles, -1, a.da[0]);            // masks a1: id 0
+            stage_run(ic<bwd6_f0(4)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<256>{}, tiles, L - 2, a.da[L - 1], L != 7);   // masks a_L: id L - 1; the first one follows the padding walk, not a stage
+        stage_run(ic<bwd6_f0(10)>{}, ic<8>{}, ic<16>{}, ic<1>{}, ic<256>{}, tiles, -1, a.da[0], true);      // masks a1: id 0
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
