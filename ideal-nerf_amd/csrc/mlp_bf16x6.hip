@@ -32,7 +32,7 @@ struct NoTileSide {
     template <int T, int S>
     __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {}
 };
-template <int F0, int NT, int KS, int OPEN_YOUNGER = 0, class BGet, class Side = NoTileSide, class Hook = NoHook>
+template <int F0, int NT, int KS, int OPEN_YOUNGER = 0, int MID_YOUNGER = 0, class BGet, class Side = NoTileSide, class Hook = NoHook>
 __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGet&& bget, WStream& ws, FragReader& fr,
                                           f32x4 (&pref)[3], Side&& side = NoTileSide{}, Hook&& after_open = NoHook{}) {
     constexpr int NP = NT * KS;
@@ -73,7 +73,9 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
         O[t] = mfma_bf(a[0], b3, O[t]);   // w1 a3
         O[t] = mfma_bf(a[2], b1, O[t]);   // w3 a1
         if constexpr (next_crosses && pi + 1 < NP) {
-            ws.open_slice();
+            // MID_YOUNGER (training, layers whose tiles are slices): the row stores issued in the second half of the slice
+            // that ends here -- none in tile 0 -- are younger than the pieces of the slice being opened
+            ws.template open_slice<(t >= 1 ? MID_YOUNGER : 0)>();
             static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
         }
         a[0] = n[0];
@@ -118,6 +120,27 @@ struct RecordSide {
         signs_relu(ic<T>{});
         store2(ic<T>{}, ic<0>{});
         store2(ic<T>{}, ic<2>{});
+    }
+    template <int T, int Q>
+    __device__ __forceinline__ void store1(ic<T>, ic<Q>) const {
+#ifdef IDN_TIMING_NO_ROW_STORES
+        return;
+#endif
+        *reinterpret_cast<f32x4*>(row + 32 * T + 8 * Q) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
+    }
+};
+// A 256 x 256 layer's tile is exactly one slice of the stream (16 k-steps x 4 fragments), and a wave issues its pieces of
+// the next slice in the FIRST half of a slice.  Tile t - 1 is therefore recorded in the SECOND half of tile t (sign bits
+// and ReLU at step 7, one row store at each of steps 8..11): those four stores are younger than the pieces the barrier at
+// the end of the tile waits for, and vmcnt retires in issue order, so that barrier waits `vmcnt(4)` and the stores get
+// the next one and a half slices to reach memory, spread over the layer instead of one burst of 32 at its end.
+struct RecordInShadow : RecordSide {
+    template <int T, int S>
+    __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {
+        if constexpr (T > 0) {
+            if constexpr (S == 7) signs_relu(ic<T - 1>{});
+            if constexpr (S >= 8 && S < 12) store1(ic<T - 1>{}, ic<S - 8>{});
+        }
     }
 };
 
@@ -223,16 +246,25 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
         // become the next layer's input pieces.  `idx` = the layer's matrix in the activation slab (LD floats per row).
         // (always_inline: left to its heuristics hipcc made the inference variant's eight identical calls a real function,
         //  with the 320 registers of O and Pt passed through scratch memory: 11x slower)
-        // A trunk layer after the first opens its first slice behind the 8 x 4 row stores (+ 1 mask store) of the layer before
-        // it, all younger than this wave's pieces of that slice.  (Never more than were issued: the count must not reach
-        // back into the pieces.)
-        constexpr int kRecordOps = 8 * 4;
+        // Training: how many vector-memory operations are younger than a wave's pieces of the slice a layer opens FIRST:
+        // after a layer recorded in the shadow (above) the 4 row stores of tile 6 + the 4 of tile 7 (+ the mask store); after a
+        // layer recorded at its end 32 + 1.  Never more than were issued (the count must not reach back into the pieces): 8
+        // serves both, and the one code instance of layers 1..4 follows both kinds.
+        constexpr int kOpenYounger = 8, kMidYounger = 4;
         auto layer = [&](auto F0c, auto NTc, auto KSc, auto LDc, const float* bias_l, auto&& bget, int idx, auto&& hook) __attribute__((always_inline)) {
             constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KS = decltype(KSc)::value, LD = decltype(LDc)::value;
+            constexpr bool tile_is_slice = NT == 8 && KS == 16 && F0 % kSliceFrags == 0;
             if constexpr (SAVE) {
-                const RecordSide rec{O, mk, a.acts + (long)act_off(idx) * a.p_pad + P * LD + 4 * h};
-                run_layer<F0, NT, KS, (F0 > 0 ? kRecordOps : 0)>(O, bias_l, bget, ws, fr, pref, NoTileSide{}, hook);
-                static_for<NT>([&](auto T) { rec.whole(T); });
+                float* row = a.acts + (long)act_off(idx) * a.p_pad + P * LD + 4 * h;
+                if constexpr (tile_is_slice) {
+                    const RecordInShadow rec{{O, mk, row}};
+                    run_layer<F0, NT, KS, kOpenYounger, kMidYounger>(O, bias_l, bget, ws, fr, pref, rec, hook);
+                    rec.whole(ic<NT - 1>{});
+                } else {
+                    const RecordSide rec{O, mk, row};
+                    run_layer<F0, NT, KS, (F0 > 0 ? kOpenYounger : 0)>(O, bias_l, bget, ws, fr, pref, NoTileSide{}, hook);
+                    static_for<NT>([&](auto T) { rec.whole(T); });
+                }
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(idx - kActA1, a.p_pad, tile * 4 + wave, lane);
                 *mp = u32x4{mk[0], mk[1], mk[2], mk[3]};
@@ -270,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
             };
             if constexpr (SAVE) {
                 const RecordSide rec{O, mk, a.acts + (long)act_off(kActV1) * a.p_pad + P * 128 + 4 * h};
-                run_layer<f0(8), 5, 18, kRecordOps>(O, bias_h + bias_off(8), bget8, ws, fr, pref);
+                run_layer<f0(8), 5, 18, kOpenYounger>(O, bias_h + bias_off(8), bget8, ws, fr, pref);
                 static_for<4>([&](auto T) { rec.whole(T); });
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(kActV1 - kActA1, a.p_pad, tile * 4 + wave, lane);

@@ -402,7 +402,7 @@ namespace x6 {
 
 // One stage's MFMAs: zeroed accumulators, KS k-steps of six piece products per tile (run_layer of mlp_bf16x6.hip
 // without the bias).  LAST: nothing is read ahead past this stage (the padding before the trunk / the end of the pass).
-template <int F0, int NT, int KS, bool LAST, int OPEN_YOUNGER, class BGet, class Side>
+template <int F0, int NT, int KS, bool LAST, int OPEN_YOUNGER, int MID_YOUNGER, class BGet, class Side>
 __device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, FragReader& fr, f32x4 (&pref)[3], Side&& side, bool behind_stores) {
     constexpr int NP = NT * KS;
     static_assert(F0 % 4 == 0, "quads");
@@ -445,7 +445,9 @@ __device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, 
         O[t] = mfma_bf(a[0], b3, O[t]);
         O[t] = mfma_bf(a[2], b1, O[t]);
         if constexpr (next_crosses && pi + 1 < NP) {
-            ws.open_slice();
+            // MID_YOUNGER (trunk stages, whose tiles are slices): the row stores issued in the second half of the slice that
+            // ends here -- none in tile 0 -- are younger than the pieces of the slice being opened
+            ws.template open_slice<(t >= 1 ? MID_YOUNGER : 0)>();
             static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
         }
         a[0] = n[0];
@@ -492,8 +494,24 @@ struct MaskStoreSide {
         store2(ic<T>{}, ic<0>{});
         store2(ic<T>{}, ic<2>{});
     }
+    template <int T, int Q>
+    __device__ __forceinline__ void store1(ic<T>, ic<Q>) const {
+#ifdef IDN_TIMING_NO_ROW_STORES
+        return;
+#endif
+        *reinterpret_cast<f32x4*>(row + 32 * T + 8 * Q) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
+    }
+    // A trunk stage's tile is exactly one slice of the stream, and a wave issues its pieces of the next slice in the FIRST
+    // half of a slice: tile t - 1 is masked at step 7 of tile t and written at steps 8..11 -- four stores younger than the
+    // pieces the barrier at the end of the tile waits for (`vmcnt(4)` there: vmcnt retires in issue order), with one and a
+    // half slices to reach memory, instead of a burst of 32 at the end of the stage.  Other stages: after the stage.
     template <int T, int S>
-    __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {}
+    __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {
+        if constexpr (KS == 16 && T > 0) {
+            if constexpr (S == 7) apply(ic<T - 1>{});
+            if constexpr (S >= 8 && S < 12) store1(ic<T - 1>{}, ic<S - 8>{});
+        }
+    }
 };
 
 constexpr int kDelta6Lds = kRingFrags * kFragBytes;
@@ -557,10 +575,11 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
             const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
             if (next_id >= 0) mask_nxt = mask_load(next_id);
             const MaskStoreSide<decltype(KSc)::value> side{O, mk, dst + P * LD + 4 * h};
-            // a trunk stage after the first opens its first slice behind the 8 x 4 row stores of the stage before it
-            constexpr int kYounger = decltype(F0c)::value >= bwd6_f0(4) ? 8 * 4 : 0;
-            run_stage6<decltype(F0c)::value, NT, decltype(KSc)::value, decltype(LASTc)::value != 0, kYounger>(O, bget, ws, fr, pref, side, behind_stores);
-            static_for<NT>([&](auto T) { side.whole(T); });
+            // a trunk stage after the first opens its first slice behind the row stores of tiles 6 and 7 of the stage before it
+            constexpr bool trunk = decltype(F0c)::value >= bwd6_f0(4);
+            run_stage6<decltype(F0c)::value, NT, decltype(KSc)::value, decltype(LASTc)::value != 0, (trunk ? 8 : 0), (trunk ? 4 : 0)>(O, bget, ws, fr, pref, side, behind_stores);
+            if constexpr (trunk) side.whole(ic<NT - 1>{});
+            else static_for<NT>([&](auto T) { side.whole(T); });
             static_for<NT>([&](auto T) { convert_tile<false>(O[decltype(T)::value], Pt[decltype(T)::value]); });
         };
         // 0: rgb_linear^T : d rgb (3) -> delta of views_linears.2, masked by its output v3
