@@ -100,6 +100,7 @@ struct RecordSide {
     f32x16* O;
     uint32_t* mk;
     float* row;
+    float* lin;   // timing-only experiment: first float of this wave's 32 rows + 4 lane
     template <int T>
     __device__ __forceinline__ void signs_relu(ic<T>) const {
         collect_signs<T>(O[T], mk);
@@ -124,6 +125,10 @@ struct RecordSide {
     template <int T, int Q>
     __device__ __forceinline__ void store1(ic<T>, ic<Q>) const {
 #ifdef IDN_TIMING_NO_ROW_STORES
+        return;
+#endif
+#ifdef IDN_TIMING_LINEAR_ROW_STORES   // timing-only (wrong layout): the same bytes into the same 32 rows, 1 KiB contiguous per instruction
+        *reinterpret_cast<f32x4*>(lin + (T * 4 + Q) * 256) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
         return;
 #endif
         *reinterpret_cast<f32x4*>(row + 32 * T + 8 * Q) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
@@ -257,11 +262,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
             if constexpr (SAVE) {
                 float* row = a.acts + (long)act_off(idx) * a.p_pad + P * LD + 4 * h;
                 if constexpr (tile_is_slice) {
-                    const RecordInShadow rec{{O, mk, row}};
+                    const RecordInShadow rec{{O, mk, row, row - (P - (P & ~31L)) * LD - 4 * h + 4 * lane}};
                     run_layer<F0, NT, KS, kOpenYounger, kMidYounger>(O, bias_l, bget, ws, fr, pref, rec, hook);
                     rec.whole(ic<NT - 1>{});
                 } else {
-                    const RecordSide rec{O, mk, row};
+                    const RecordSide rec{O, mk, row, row};
                     run_layer<F0, NT, KS, (F0 > 0 ? kOpenYounger : 0)>(O, bias_l, bget, ws, fr, pref, NoTileSide{}, hook);
                     static_for<NT>([&](auto T) { rec.whole(T); });
                 }
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
                 else return pd_p[q][s - 16];
             };
             if constexpr (SAVE) {
-                const RecordSide rec{O, mk, a.acts + (long)act_off(kActV1) * a.p_pad + P * 128 + 4 * h};
+                const RecordSide rec{O, mk, a.acts + (long)act_off(kActV1) * a.p_pad + P * 128 + 4 * h, nullptr};
                 run_layer<f0(8), 5, 18, kOpenYounger>(O, bias_h + bias_off(8), bget8, ws, fr, pref);
                 static_for<4>([&](auto T) { rec.whole(T); });
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

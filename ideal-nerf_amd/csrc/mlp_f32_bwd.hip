@@ -469,6 +469,7 @@ struct MaskStoreSide {
     f32x16* O;
     const uint32_t* mk;   // dword k = tiles 2k, 2k+1, value i of the pair at bit 31 - i
     float* row;           // this lane's row of the delta matrix + 4 h
+    float* lin;           // timing-only experiment: first float of this wave's 32 rows + 4 lane
     template <int T>
     __device__ __forceinline__ void apply(ic<T>) const {
         const uint32_t w = mk[T >> 1];
@@ -497,6 +498,10 @@ struct MaskStoreSide {
     template <int T, int Q>
     __device__ __forceinline__ void store1(ic<T>, ic<Q>) const {
 #ifdef IDN_TIMING_NO_ROW_STORES
+        return;
+#endif
+#ifdef IDN_TIMING_LINEAR_ROW_STORES   // timing-only (wrong layout): the same bytes into the same 32 rows, 1 KiB contiguous per instruction
+        *reinterpret_cast<f32x4*>(lin + (T * 4 + Q) * 256) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
         return;
 #endif
         *reinterpret_cast<f32x4*>(row + 32 * T + 8 * Q) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
             const u32x4 mv = mask_nxt;
             const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
             if (next_id >= 0) mask_nxt = mask_load(next_id);
-            const MaskStoreSide<decltype(KSc)::value> side{O, mk, dst + P * LD + 4 * h};
+            const MaskStoreSide<decltype(KSc)::value> side{O, mk, dst + P * LD + 4 * h, dst + (P & ~31L) * LD + 4 * lane};
             // a trunk stage after the first opens its first slice behind the row stores of tiles 6 and 7 of the stage before it
             constexpr bool trunk = decltype(F0c)::value >= bwd6_f0(4);
             run_stage6<decltype(F0c)::value, NT, decltype(KSc)::value, decltype(LASTc)::value != 0, (trunk ? 8 : 0), (trunk ? 4 : 0)>(O, bget, ws, fr, pref, side, behind_stores);
