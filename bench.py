@@ -72,6 +72,8 @@ def launch_ranks(n, argv, script=None, timeout=None):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    if timeout is None:   # ranks that hang (a peer that never joined a collective) end the run instead of outliving it
+        timeout = float(os.environ.get("IDN_LAUNCH_TIMEOUT_S", "1500"))
     try:
         proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
     except subprocess.TimeoutExpired as e:

@@ -420,11 +420,12 @@ def test_bench_two_ranks_from_a_plain_start(dev):
     the transport."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, IDN_DIST_BACKEND="gloo", IDN_FORCE_DEVICE="0")
+    # (a rank that never reaches the rendezvous is an error after 90 s, not a silent wait)
+    env = dict(os.environ, IDN_DIST_BACKEND="gloo", IDN_FORCE_DEVICE="0", IDN_DIST_TIMEOUT_S="90")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "96"],
-                       env=env, capture_output=True, text=True, timeout=600)
+                       env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout
@@ -433,7 +434,7 @@ def test_bench_two_ranks_from_a_plain_start(dev):
     assert res["config"]["band_rows"] == [48, 48] and res["steps"] == 2
     assert res["value"] > 0 and res["roofline"]["frac"] is not None and res["roofline"]["traffic"] is None
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "96",
-                          "--no-cpu-baseline", "--no-side-mode"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--no-side-mode"], env=env, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stderr[-3000:]
     r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][-1])
     assert r1["n_gpus"] == 1 and r1["ranks"] == 1 and r1["config"]["rays_per_step"] == res["config"]["rays_per_step"]
