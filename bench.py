@@ -74,11 +74,25 @@ def launch_ranks(n, argv, script=None, timeout=None):
            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
     if timeout is None:   # ranks that hang (a peer that never joined a collective) end the run instead of outliving it
         timeout = float(os.environ.get("IDN_LAUNCH_TIMEOUT_S", "1500"))
+    import signal
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)   # its own process group
     try:
-        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
-    except subprocess.TimeoutExpired as e:
+        out, _ = child.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        # the whole group -- the launcher AND its ranks -- by its exact id (never by name): first politely, then not
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=15)
+                break
+            except subprocess.TimeoutExpired:
+                continue
         sys.stderr.write(f"bench.py: the {n}-rank run did not finish within {timeout} s\n")
         return 124
+    proc = subprocess.CompletedProcess(cmd, child.returncode, out, None)
     line = None
     for ln in proc.stdout.splitlines():
         try:

@@ -4,6 +4,7 @@ keeps the reference's names/shapes/semantics, the product path refuses CPU tenso
 the multi-rank tiling works over gloo with world_size 2.  No GPU compute here."""
 import ctypes as C
 import os
+import time
 import re
 import subprocess
 import sys
@@ -510,6 +511,20 @@ def test_bench_launcher_propagates_a_failed_rank(tmp_path, capsys):
     rc = bench.launch_ranks(2, [], script=str(quiet), timeout=300)
     out = capsys.readouterr()
     assert rc == 1 and out.out.strip() == "" and "hello from a rank" in out.err
+    hang = tmp_path / "hang_rank.py"
+    hang.write_text("import os, time\nopen(os.environ['IDN_TEST_PIDFILE'] + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    os.environ["IDN_TEST_PIDFILE"] = str(tmp_path / "pid")
+    try:
+        t0 = time.time()
+        rc = bench.launch_ranks(2, [], script=str(hang), timeout=20)
+        out = capsys.readouterr()
+        assert rc == 124 and out.out.strip() == "" and time.time() - t0 < 90
+        time.sleep(1.0)
+        for r in ("0", "1"):      # the ranks went down with the launcher (killed by process-group id)
+            pid = int(open(str(tmp_path / "pid") + r).read())
+            assert not os.path.exists(f"/proc/{pid}") or open(f"/proc/{pid}/stat").read().split()[2] == "Z", pid
+    finally:
+        os.environ.pop("IDN_TEST_PIDFILE", None)
     good = tmp_path / "good_rank.py"
     good.write_text("import os, sys, json\n"
                     "assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
