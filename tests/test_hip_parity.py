@@ -657,6 +657,43 @@ def test_train_step_matches_oracle_autograd_ragged(idn, dev):
             check_grads(net.face_nerf_fine.named_parameters(), pf, True, n_rays)
 
 
+def test_train_step_is_bit_reproducible_at_bench_scale(idn, dev):
+    """The training kernels keep row stores in flight across slice barriers behind hand-counted `vmcnt` waits (weight
+    pieces are waited for, the stores issued after them are not) and reload row registers in place behind counted waits:
+    a count that reached back into a piece would read a weight slice before it has landed -- sometimes.  Nothing in the
+    step uses atomics, so every run of the same step must give the same bits: 12 runs of forward + backward on 3072 rays
+    x (64 + 192) points (the bench's step: every CU busy, 36 GB through HBM) against the first."""
+    from idealnerf_amd.helper import img2mse
+    net, syn = _train_net(idn, dev)
+    rs = np.random.RandomState(7)
+    H = W = 96
+    rec = idn.ops.frame_rays(syn["c2w"], H, W, syn["focal"] * 3, NEAR, FAR, device=dev)
+    sel = T(rs.choice(H * W, size=3072, replace=False)).to(dev)
+    rays = rec[sel].contiguous()
+    bc = T(rs.uniform(0, 1, size=(3072, 3)).astype(np.float32)).to(dev)
+    tgt = T(rs.uniform(0, 1, size=(3072, 3)).astype(np.float32)).to(dev)
+    first = None
+    for run in range(12):
+        aud = syn["aud"].to(dev).requires_grad_(True)
+        lat = syn["latent"].to(dev).requires_grad_(True)
+        for p_ in net.parameters():
+            p_.grad = None
+        ret = net.render_rays(rays, bc, aud, syn["c2w"], lat, syn["expr"].to(dev))
+        loss = img2mse(ret["rgb_map"], tgt) + img2mse(ret["rgb0"], tgt) + 10 * (torch.norm(lat) * 0.0005)
+        loss.backward()
+        got = {"loss": loss.detach().clone(), "rgb": ret["rgb_map"].detach().clone(), "aud": aud.grad.clone(), "lat": lat.grad.clone()}
+        for tag, m in (("c", net.face_nerf_coarse), ("f", net.face_nerf_fine)):
+            for k, p_ in m.named_parameters():
+                if p_.grad is not None:
+                    got[f"{tag}.{k}"] = p_.grad.clone()
+        assert all(bool(torch.isfinite(v).all()) for v in got.values())
+        if first is None:
+            first = got
+        else:
+            diff = [k for k in first if not torch.equal(first[k], got[k])]
+            assert not diff, (run, diff)
+
+
 # --------------------------------------------------------------------------- a11: head + torso composite
 def _torso_setup(idn, dev, n=48):
     torch.manual_seed(4321)  # the audio net is torch-initialised: same instance in every process
