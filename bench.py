@@ -324,8 +324,8 @@ def bench_train(args):
                       "dtype": "f32", "data": "synthetic",
                       "arithmetic": "families named `_x6`: every fp32 operand as the exact sum of three bf16 pieces, six piece products per "
                                     "product on the bf16 MFMA pipe, fp32 accumulate (error <= 2^-23 per product, as an fp32 fma chain; "
-                                    "gradient parity tests unchanged); the others fp32 MFMA / VALU.  IDN_TRAIN_PRECISION=f32 and a build with "
-                                    "-DIDN_DELTA_X6=0 -DIDN_DW_X6=0 put everything on the fp32 pipe",
+                                    "gradient parity tests unchanged); the others fp32 MFMA / VALU.  IDN_TRAIN_PRECISION=f32 IDN_BACKWARD_PIPE=f32 "
+                                    "put everything on the fp32 pipe",
                       "config": {"workload": "BASELINE configs[2]: May HeadNeRF train step, N_rand=3072 mouth_rays=512 "
                                              "dim_aud=64 dim_expr=76, perturb=1"},
                       "roofline": {"bound": "mfma", "kernel": "the step's MFMA kernel families (see `kernels`): forward with saved activations, delta chain, "

@@ -12,6 +12,7 @@
 // Activations come from the training variant of the MLP kernel as row-major matrices
 // (idn_internal.h, "activation slab").  Everything is deterministic: no float atomics.
 #include "idn_internal.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace idn {
@@ -826,8 +827,20 @@ size_t bwd_workspace_bytes(int64_t n_points) {
 
 // part[split][N][K] = A[:, :N]^T . B[:, :K] over point splits; returns the split count
 enum { kPipeX6 = 0, kPipeF32 = 1 };   // which matrix pipe a 256 x 256 GEMM runs on (the other shapes: fp32)
+// The backward's pipe for the delta chain and the 256 x 256 GEMMs: the six-piece bf16 arithmetic unless the process was
+// started with IDN_BACKWARD_PIPE=f32 (read once; the A/B arm and the fallback, exercised by the GPU tests) or the
+// library was built with -DIDN_DELTA_X6=0 / -DIDN_DW_X6=0.
+static int env_pipe_f32() {
+    static const int v = [] {
+        const char* e = getenv("IDN_BACKWARD_PIPE");
+        return (e && e[0] == 'f' && e[1] == '3' && e[2] == '2' && e[3] == 0) ? 1 : 0;
+    }();
+    return v;
+}
+static int default_gemm_pipe() { return (IDN_DW_X6 && !env_pipe_f32()) ? kPipeX6 : kPipeF32; }
 static int run_tn_partials(const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part,
-                           int* splits_out, hipStream_t s, float* cpart = nullptr, int pipe = IDN_DW_X6 ? kPipeX6 : kPipeF32) {
+                           int* splits_out, hipStream_t s, float* cpart = nullptr, int pipe = -1) {
+    if (pipe < 0) pipe = default_gemm_pipe();
     int ntw, ktw;
     if (N == 256 && K == 256) { ntw = 4; ktw = 4; }
     else if (N == 256 && K == 64) { ntw = 4; ktw = 1; }
@@ -983,7 +996,7 @@ static int run_tn_q(ReduceQueue& q, const float* A, int lda, int N, const float*
 // out = A^T B (rows x cols of it); db (optional, `db_cols` entries) = column sums of A, from the same pass over A
 static int run_tn(ReduceQueue& q, const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* out,
                   int ldo, int rows, int cols, hipStream_t s, float* db = nullptr, int db_cols = 0,
-                  int pipe = IDN_DW_X6 ? kPipeX6 : kPipeF32) {
+                  int pipe = -1) {
     int splits = 0;
     const float *part, *cpart;
     if (int e = run_tn_q(q, A, lda, N, B, ldb, K, P, &splits, &part, &cpart, db != nullptr, s, pipe)) return e;
@@ -1043,13 +1056,13 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
 #define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
     // All pre-activation deltas in one fused pass over the points (mlp_f32_bwd.hip): dV[0] = delta of
     // views_linears.2, dV[1] = views_linears.1, dV0[:, :128] = views_linears.0 (col 128 = d sigma), dA[l] = pts_linears.l
-#if IDN_DELTA_X6
-    TRY(launch_pack_bf16x6_bwd(p, w.wbwd, s));
-    TRY(launch_delta_chain_x6(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
-#else
-    TRY(launch_pack_f32_bwd(p, w.wbwd, s));
-    TRY(launch_delta_chain(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
-#endif
+    if (IDN_DELTA_X6 && !env_pipe_f32()) {
+        TRY(launch_pack_bf16x6_bwd(p, w.wbwd, s));
+        TRY(launch_delta_chain_x6(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
+    } else {   // (the workspace's stream buffer is sized for the larger of the two streams)
+        TRY(launch_pack_f32_bwd(p, w.wbwd, s));
+        TRY(launch_delta_chain(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
+    }
     // weight and bias gradients: dW_l = delta_l^T a_{l-1} (contraction over the points), db_l = column sums
     ReduceQueue q(w.part, w.cpart);
     TRY(run_tn(q, w.dRGB, 64, 64, v_l(3), 128, 128, Pp, gr.rgb_w, 128, 3, 128, s, gr.rgb_b, 3));

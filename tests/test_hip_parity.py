@@ -7,6 +7,8 @@ out); everything upstream of that boundary is fp32 arithmetic whose roundings di
 between a CPU BLAS and MFMA by ~1e-6, so end-to-end index agreement is reported as a
 flip rate and bounded, not promised to be zero (hard part 1).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -655,6 +657,18 @@ def test_train_step_matches_oracle_autograd_ragged(idn, dev):
         check_grads(net.face_nerf_coarse.named_parameters(), pc, False, n_rays)
         if ni:
             check_grads(net.face_nerf_fine.named_parameters(), pf, True, n_rays)
+
+
+def test_training_on_the_fp32_pipe_still_passes_the_gradient_tests(dev):
+    """The fallback arm: IDN_TRAIN_PRECISION=f32 (forward on the fp32 MFMA kernel) + IDN_BACKWARD_PIPE=f32 (fp32 delta
+    chain and fp32 256 x 256 GEMMs) are read once per process, so the gradient tests run again in a fresh one."""
+    import subprocess
+    import sys
+    env = dict(os.environ, IDN_TRAIN_PRECISION="f32", IDN_BACKWARD_PIPE="f32")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "train_step_gradients_golden or backward_kernels_vs_fp64 or train_step_matches_oracle_autograd_ragged"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_train_step_is_bit_reproducible_at_bench_scale(idn, dev):
