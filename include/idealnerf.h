@@ -266,7 +266,8 @@ size_t idealnerf_train_acts_floats(int64_t n_points);
 /* idealnerf_query_rays_fwd that also records what the backward needs (the post-ReLU
  * activations of all 11 hidden layers and both encodings).  precision: IDN_PREC_F32 or IDN_PREC_BF16X6 (the
  * fp32-grade arithmetics; `packed` must be that precision's stream).  idealnerf_pass_bwd itself computes the delta
- * chain and the 256 x 256 weight-gradient products with the six-piece bf16 arithmetic. */
+ * chain and the 256 x 256 weight-gradient products with the six-piece bf16 arithmetic, or on
+ * the fp32 matrix pipe when the process was started with IDN_BACKWARD_PIPE=f32. */
 int idealnerf_query_rays_train_fwd(const float* packed, const float* folded, int precision, const float* rays,
                                    const float* z, int64_t n_rays, int n_samples, float* raw, float* acts,
                                    void* stream);
