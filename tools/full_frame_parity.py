@@ -1,5 +1,5 @@
 """One-off validation (minutes of CPU time): the WHOLE 512x512 bench frame from the CPU oracle, row band by
-row band, against the HIP path in its fp32, mixed and bf16x3 modes.  Writes a JSON summary.
+row band, against the HIP path in its fp32, bf16x6, fp16x3, mixed and bf16x3 modes.  Writes a JSON summary.
 
     python tools/full_frame_parity.py [out.json]          (on the GPU box; prints a line per band)
 """
@@ -25,7 +25,7 @@ def main():
     bc = syn["bc"].reshape(-1, 3).contiguous().to(dev)
     frames = {}
     with torch.no_grad():
-        for mode, (pc_, pf_) in (("f32", ("f32", "f32")), ("fp16x3", ("fp16x3", "fp16x3")), ("mixed", ("f32", "bf16x3")), ("bf16x3", ("bf16x3", "bf16x3"))):
+        for mode, (pc_, pf_) in (("f32", ("f32", "f32")), ("bf16x6", ("bf16x6", "bf16x6")), ("fp16x3", ("fp16x3", "fp16x3")), ("mixed", ("f32", "bf16x3")), ("bf16x3", ("bf16x3", "bf16x3"))):
             coarse.precision, fine.precision = pc_, pf_
             rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], device=dev)
             o = ops.render_rays_fwd(rays, bc, coarse.packed_weights(), coarse.folded_bias(aud, expr, latent), fine.packed_weights(),
