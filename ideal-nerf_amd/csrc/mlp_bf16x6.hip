@@ -255,7 +255,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
         // after a layer recorded in the shadow (above) the 4 row stores of tile 6 + the 4 of tile 7 (+ the mask store); after a
         // layer recorded at its end 32 + 1.  Never more than were issued (the count must not reach back into the pieces): 8
         // serves both, and the one code instance of layers 1..4 follows both kinds.
-        constexpr int kOpenYounger = 8, kMidYounger = 4;
+#ifndef IDN_TEST_OPEN_YOUNGER        // (overridden only by the audit tool's own negative test: tests/test_boundary_cpu.py)
+#define IDN_TEST_OPEN_YOUNGER 8
+#define IDN_TEST_MID_YOUNGER 4
+#endif
+        constexpr int kOpenYounger = IDN_TEST_OPEN_YOUNGER, kMidYounger = IDN_TEST_MID_YOUNGER;
         auto layer = [&](auto F0c, auto NTc, auto KSc, auto LDc, const float* bias_l, auto&& bget, int idx, auto&& hook) __attribute__((always_inline)) {
             constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KS = decltype(KSc)::value, LD = decltype(LDc)::value;
             constexpr bool tile_is_slice = NT == 8 && KS == 16 && F0 % kSliceFrags == 0;

@@ -403,20 +403,15 @@ namespace x6 {
 // One stage's MFMAs: zeroed accumulators, KS k-steps of six piece products per tile (run_layer of mlp_bf16x6.hip
 // without the bias).  LAST: nothing is read ahead past this stage (the padding before the trunk / the end of the pass).
 template <int F0, int NT, int KS, bool LAST, int OPEN_YOUNGER, int MID_YOUNGER, class BGet, class Side>
-__device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, FragReader& fr, f32x4 (&pref)[3], Side&& side, bool behind_stores) {
+__device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, FragReader& fr, f32x4 (&pref)[3], Side&& side) {
     constexpr int NP = NT * KS;
     static_assert(F0 % 4 == 0, "quads");
     static_for<NT>([&](auto T) { static_for<16>([&](auto R) { O[decltype(T)::value][decltype(R)::value] = 0.0f; }); });
     if constexpr (F0 % kSliceFrags == 0) {
-        // behind_stores (wave-uniform): the stage before this one has just issued its 8 x 4 row stores, all of them younger
-        // than this wave's pieces of the slice being opened: they stay in flight.  (Never more than were issued: the
-        // count must not reach back into the pieces.)
-        if constexpr (OPEN_YOUNGER > 0) {
-            if (behind_stores) ws.template open_slice<OPEN_YOUNGER>();
-            else ws.open_slice();
-        } else {
-            ws.open_slice();
-        }
+        // OPEN_YOUNGER: the stage before this one has issued that many row stores after this wave's last piece of the slice
+        // being opened: they stay in flight.  (Never more than were issued: the count must not reach back into the pieces --
+        // tools/audit_asm_loads.py counts them on every path.)
+        ws.template open_slice<OPEN_YOUNGER>();
         static_for<3>([&](auto Q) { pref[decltype(Q)::value] = fr.template issue<F0 + decltype(Q)::value>(); });
         retire3<0>(pref);
     }
@@ -574,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
             return Pt[s >> 1].p[q][s & 1];
         };
         // one stage: MFMAs, then mask (this stage's ReLU bits, loaded a stage ahead), store the delta rows, split into pieces
-        auto stage_run = [&](auto F0c, auto NTc, auto KSc, auto LASTc, auto LDc, auto&& bget, int next_id, float* dst, bool behind_stores) __attribute__((always_inline)) {
+        auto stage_run = [&](auto F0c, auto NTc, auto KSc, auto LASTc, auto LDc, auto YOUNGERc, auto&& bget, int next_id, float* dst) __attribute__((always_inline)) {
             constexpr int NT = decltype(NTc)::value, LD = decltype(LDc)::value;
             const u32x4 mv = mask_nxt;
             const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
@@ -582,30 +577,33 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
             const MaskStoreSide<decltype(KSc)::value> side{O, mk, dst + P * LD + 4 * h, dst + (P & ~31L) * LD + 4 * lane};
             // a trunk stage after the first opens its first slice behind the row stores of tiles 6 and 7 of the stage before it
             constexpr bool trunk = decltype(F0c)::value >= bwd6_f0(4);
-            run_stage6<decltype(F0c)::value, NT, decltype(KSc)::value, decltype(LASTc)::value != 0, (trunk ? 8 : 0), (trunk ? 4 : 0)>(O, bget, ws, fr, pref, side, behind_stores);
+            run_stage6<decltype(F0c)::value, NT, decltype(KSc)::value, decltype(LASTc)::value != 0, decltype(YOUNGERc)::value, (trunk ? 4 : 0)>(O, bget, ws, fr, pref, side);
             if constexpr (trunk) side.whole(ic<NT - 1>{});
             else static_for<NT>([&](auto T) { side.whole(T); });
             static_for<NT>([&](auto T) { convert_tile<false>(O[decltype(T)::value], Pt[decltype(T)::value]); });
         };
         // 0: rgb_linear^T : d rgb (3) -> delta of views_linears.2, masked by its output v3
-        stage_run(ic<bwd6_f0(0)>{}, ic<4>{}, ic<1>{}, ic<0>{}, ic<128>{}, [&](auto Q, auto) { return in_rgb[decltype(Q)::value]; }, 9, a.dv2, false);
+        stage_run(ic<bwd6_f0(0)>{}, ic<4>{}, ic<1>{}, ic<0>{}, ic<128>{}, ic<0>{}, [&](auto Q, auto) { return in_rgb[decltype(Q)::value]; }, 9, a.dv2);
         // 1: views_linears.2^T -> delta of views_linears.1 (mask v2);  2: views_linears.1^T -> views_linears.0 (mask v1)
-        stage_run(ic<bwd6_f0(1)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<128>{}, tiles, 8, a.dv1, false);
-        stage_run(ic<bwd6_f0(2)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<256>{}, tiles, 7, a.dv0, false);
+        stage_run(ic<bwd6_f0(1)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<128>{}, ic<0>{}, tiles, 8, a.dv1);
+        stage_run(ic<bwd6_f0(2)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<256>{}, ic<0>{}, tiles, 7, a.dv0);
         // 3: views_linears.0[:, :256]^T + alpha_linear^T (d sigma as k-channel 128) -> delta of pts_linears.7 (mask a8)
-        stage_run(ic<bwd6_f0(3)>{}, ic<8>{}, ic<9>{}, ic<1>{}, ic<256>{},
+        stage_run(ic<bwd6_f0(3)>{}, ic<8>{}, ic<9>{}, ic<1>{}, ic<256>{}, ic<0>{},
                   [&](auto Q, auto S_) {
                       constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
                       if constexpr (s < 8) return Pt[s >> 1].p[q][s & 1];
                       else return in_sig[q];
                   },
-                  6, a.da[7], false);
+                  6, a.da[7]);
         finish_pass<2 * kBwdHeadFrags, 2 * kBwdTrunk0>(ws);   // walk the padding up to the trunk stages
-        // 4..9: pts_linears.7 .. .2 ^T, one code instance (a trunk stage is four ring lengths); then pts_linears.1^T
+        // 4: pts_linears.7^T follows the padding walk, not a stage: its first slice is opened with a full wait.
+        // 5..9: pts_linears.6 .. .2 ^T, one code instance (a trunk stage is four ring lengths), each opening its first slice
+        // behind the 8 row stores of tiles 6 and 7 of the stage before it; then pts_linears.1^T.
+        stage_run(ic<bwd6_f0(4)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<256>{}, ic<0>{}, tiles, 5, a.da[6]);                   // masks a7: id 6
 #pragma unroll 1
-        for (int L = 7; L >= 2; --L)
-            stage_run(ic<bwd6_f0(4)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<256>{}, tiles, L - 2, a.da[L - 1], L != 7);   // masks a_L: id L - 1; the first one follows the padding walk, not a stage
-        stage_run(ic<bwd6_f0(10)>{}, ic<8>{}, ic<16>{}, ic<1>{}, ic<256>{}, tiles, -1, a.da[0], true);      // masks a1: id 0
+        for (int L = 6; L >= 2; --L)
+            stage_run(ic<bwd6_f0(5)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<256>{}, ic<8>{}, tiles, L - 2, a.da[L - 1]);       // masks a_L: id L - 1
+        stage_run(ic<bwd6_f0(10)>{}, ic<8>{}, ic<16>{}, ic<1>{}, ic<256>{}, ic<8>{}, tiles, -1, a.da[0]);                 // masks a1: id 0
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();

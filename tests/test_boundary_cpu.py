@@ -301,6 +301,20 @@ def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
     vm.write_text(vm.read_text().replace("v_mov_b32_e32 v7, v6", "v_mov_b32_e32 v7, v5"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(vm)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
+    # third check: a counted vmcnt in front of a slice barrier (the training kernels keep their row stores in flight
+    # across it) must not reach back into the LDS-DMA pieces: three stores since the last piece cannot justify vmcnt(4),
+    # on the path that skips the fourth one
+    cw = tmp_path / "cw.s"
+    cw.write_text("_Z16fake_mlp_kernel4v:\n.LBB0_1:\n\tbuffer_load_dwordx4 v36, s[8:11], s28 offen lds\n"
+                  "\tglobal_store_dwordx4 v[0:1], v[2:5], off\n\tglobal_store_dwordx4 v[0:1], v[2:5], off offset:16\n"
+                  "\tglobal_store_dwordx4 v[0:1], v[2:5], off offset:32\n\ts_cbranch_scc1 .LBB0_2\n"
+                  "\tglobal_store_dwordx4 v[0:1], v[2:5], off offset:48\n.LBB0_2:\n"
+                  "\t;;#ASMSTART\n\ts_waitcnt vmcnt(4)\n\t;;#ASMEND\n\ts_barrier\n\ts_cbranch_scc0 .LBB0_1\n\ts_endpgm\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(cw)], capture_output=True, text=True)
+    assert r.returncode == 1 and "a piece may still be in flight" in r.stdout, r.stdout
+    cw.write_text(cw.read_text().replace("\ts_cbranch_scc1 .LBB0_2\n", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), str(cw)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
 
 
 def test_config_files_parse_like_the_reference(idn):

@@ -16,6 +16,10 @@ a VALU read only for instructions it can see; with accumulators in AGPRs a visib
 v_accvgpr_read always sits in between, with VGPR accumulators (two waves per SIMD, <= 256
 registers) an asm ReLU read the result early and returned garbage.
 
+Third check, same walk: a counted `s_waitcnt vmcnt(N)` in front of a slice barrier (the training kernels
+keep their row stores in flight across it) must have at least N vector-memory operations between it and the
+last LDS-DMA piece on every path.
+
 Usage: audit_asm_loads.py file.s [kernel-name-substring]
 """
 import re, sys
@@ -145,9 +149,57 @@ def audit_inflight(insts, labels, name):
     return bad
 
 
+def audit_counted_slice_waits(insts, labels, name):
+    """Third check: the slice barriers of the MLP kernels wait for this wave's LDS-DMA pieces (`buffer_load ... lds`) of
+    the slice being opened with `s_waitcnt vmcnt(N)` + `s_barrier`.  vmcnt retires in issue order, so N > 0 is only
+    right if at least N vector-memory operations (the training kernels' row stores) were issued AFTER the last piece on
+    every path that reaches the wait -- else the wait can pass with a piece still in flight.  State = operations since
+    the last piece (saturating); every (instruction, state) pair is explored once, branches and loops followed."""
+    bad, reported, seen = 0, set(), set()
+    work = [(0, 64)]          # nothing is known at kernel entry: no piece has been issued yet
+    steps = 0
+    while work and steps < 2_000_000:
+        idx, since = work.pop()
+        while idx < len(insts):
+            if (idx, since) in seen:
+                break
+            seen.add((idx, since))
+            steps += 1
+            no, code, in_asm = insts[idx]
+            op = code.split()[0] if code else ''
+            if op.startswith(('buffer_load', 'global_load', 'scratch_load', 'flat_load')) and code.rstrip().endswith(' lds'):
+                since = 0                                   # an LDS-DMA piece
+            elif op.startswith(('buffer_', 'global_', 'scratch_', 'flat_')) and not op.startswith('buffer_wbinvl') and not op.startswith('buffer_inv'):
+                since = min(since + 1, 64)
+            elif op == 's_waitcnt':
+                m = re.search(r'vmcnt\((\d+)\)', code)
+                if m and int(m.group(1)) > 0 and in_asm:
+                    nxt = next((c for _, c, a in insts[idx + 1: idx + 3] if c), '')
+                    if nxt.startswith('s_barrier') and since < int(m.group(1)) and (no,) not in reported:
+                        reported.add((no,))
+                        bad += 1
+                        print(f"  {name}: line {no}: `{code}` before a slice barrier, but only {since} vector-memory operations "
+                              f"were issued since the last LDS-DMA piece on some path: a piece may still be in flight")
+            if code.startswith('s_endpgm'):
+                break
+            if code.startswith('s_branch') or code.startswith('s_cbranch'):
+                tgt = labels.get(code.split()[1])
+                if tgt is not None:
+                    work.append((tgt, since))
+                if code.startswith('s_branch'):
+                    break
+            idx += 1
+    return bad
+
+
 def audit(lines, name):
     insts, labels = parse(lines)
-    return audit_inflight(insts, labels, name) + audit_mfma_to_asm_valu(insts, name)
+    bad = audit_inflight(insts, labels, name) + audit_mfma_to_asm_valu(insts, name)
+    # the two-slot weight ring of the MLP / delta-chain kernels: every barrier needs ALL of the wave's pieces.  (The dW GEMM's
+    # three-buffer tiles leave the pieces of the NEXT chunk in flight on purpose: there the younger operations are pieces.)
+    if "mlp_" in name or "delta_chain" in name:
+        bad += audit_counted_slice_waits(insts, labels, name)
+    return bad
 
 
 def main():
