@@ -69,7 +69,7 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
         O[t] = mfma_bf(a[1], b1, O[t]);   // w2 a1
         if constexpr (t + 1 < NT && s < 4) bias_quad<s>(O[t + 1], bias_half + 32 * (t + 1));   // the next tile starts from its bias
         O[t] = mfma_bf(a[1], b2, O[t]);   // w2 a2
-        side(ic<t>{}, ic<s>{});           // training: the finished tile t - 1 is recorded in this tile's shadow
+        side(ic<t>{}, ic<s>{});           // training, 256 x 256 layers: tile t - 1 is recorded in this tile's second half (RecordInShadow)
         O[t] = mfma_bf(a[0], b3, O[t]);   // w1 a3
         O[t] = mfma_bf(a[2], b1, O[t]);   // w3 a1
         if constexpr (next_crosses && pi + 1 < NP) {
@@ -89,13 +89,14 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
     pref[2] = a[2];
 }
 
-// Training: a layer's tiles are RECORDED when the layer is complete, all of them BEFORE any is converted -- the sign
-// bits of the 16 pre-activations into the layer's mask word, the ReLU applied in place, the 16 values into this lane's
-// row of the layer's activation matrix (`row` = its first float + 4 h; register 4 q + j of tile t is channel
-// 32 t + 8 q + 4 h + j, so a quad of registers is 16 contiguous bytes of the row).  On gfx9 stores count in vmcnt, and
-// the next slice barrier's vmcnt(0) waits for them: issued first, they complete behind the conversion's ~3 000 cycles of
-// vector work.  (Recording tile t - 1 in the MFMA shadow of tile t was tried: every slice barrier of the layer then
-// waits for a store issued half a slice earlier -- forward 4.96 -> 5.36 ms, delta chain 4.49 -> 5.34.)
+// Training: a tile is RECORDED once its accumulator is complete -- the sign bits of the 16 pre-activations into the
+// layer's mask word, the ReLU applied in place, the 16 values into this lane's row of the layer's activation matrix
+// (`row` = its first float + 4 h; register 4 q + j of tile t is channel 32 t + 8 q + 4 h + j, so a quad of registers is
+// 16 contiguous bytes of the row).  On gfx9 stores count in vmcnt, vmcnt retires in issue order, and every slice barrier
+// waits for the wave's pieces of the next slice: a store issued BEFORE those pieces delays the barrier until it has
+// reached L2.  RecordSide is the plain form, for layers whose tiles are not slices: all tiles after the layer, and all
+// of them before any is converted, so that the burst drains behind the conversion's ~3 000 cycles of vector work.
+// (Tile t - 1 at steps 0..2 of tile t -- older than the pieces -- made every barrier of the layer wait: 4.96 -> 5.36 ms.)
 struct RecordSide {
     f32x16* O;
     uint32_t* mk;

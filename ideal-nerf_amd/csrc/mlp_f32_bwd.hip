@@ -455,10 +455,11 @@ __device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, 
     pref[2] = a[2];
 }
 
-// The tiles of a stage, once the stage is complete and all of them BEFORE any is converted: the ReLU bits of the layer
-// it is the delta of are applied and the 16 values go to this lane's row of the delta matrix.  (Stores count in vmcnt on
-// gfx9 and the next slice barrier's vmcnt(0) waits for them: issued first, they complete behind the conversion's vector
-// work.  In the MFMA shadow of the next tile they made every slice barrier of the stage wait: 4.49 -> 5.34 ms.)
+// A tile of a stage, once its accumulator is complete: the ReLU bits of the layer it is the delta of are applied and the
+// 16 values go to this lane's row of the delta matrix.  Stores count in vmcnt on gfx9, vmcnt retires in issue order, and
+// every slice barrier waits for the wave's pieces of the next slice, so WHEN a store is issued matters (mlp_bf16x6.hip,
+// RecordSide / RecordInShadow): head stages do it after the stage, all tiles before any is converted; trunk stages, whose
+// tile is one slice, in the second half of the next tile (operator() below).
 template <int KS>
 struct MaskStoreSide {
     f32x16* O;
