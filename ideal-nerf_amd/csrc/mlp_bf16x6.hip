@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
     nxt = cur;
     f32x4 pref[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        DIAG_ONLY(const unsigned long long t_tile = clock64(); dg.begin();)
         const long P = tile * 128 + wave * 32 + m;
         const bool valid = P < a.n_points;
         const long Pc = valid ? P : a.n_points - 1;
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
             pack_feats(pd_f, pd_p, ic<2>{});
         }
 
+        DIAG_END(dg, kDgInput);
         PTile6 Pt[8];
         f32x16 O[8];
         auto tiles = [&](auto Q, auto S_) {
@@ -269,19 +271,24 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
                 if constexpr (tile_is_slice) {
                     const RecordInShadow rec{{O, mk, row, row - (P - (P & ~31L)) * LD - 4 * h + 4 * lane}};
                     run_layer<F0, NT, KS, kOpenYounger, kMidYounger>(O, bias_l, bget, ws, fr, pref, rec, hook);
+                    DIAG_BEGIN(dg);
                     rec.whole(ic<NT - 1>{});
                 } else {
                     const RecordSide rec{O, mk, row, row};
                     run_layer<F0, NT, KS, (F0 > 0 ? kOpenYounger : 0)>(O, bias_l, bget, ws, fr, pref, NoTileSide{}, hook);
+                    DIAG_BEGIN(dg);
                     static_for<NT>([&](auto T) { rec.whole(T); });
                 }
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(idx - kActA1, a.p_pad, tile * 4 + wave, lane);
                 *mp = u32x4{mk[0], mk[1], mk[2], mk[3]};
                 convert_layer<NT, false>(O, Pt);
+                DIAG_END(dg, kDgBoundary);
             } else {
                 run_layer<F0, NT, KS>(O, bias_l, bget, ws, fr, pref, NoTileSide{}, hook);
+                DIAG_BEGIN(dg);
                 convert_layer<NT, true>(O, Pt);
+                DIAG_END(dg, kDgBoundary);
             }
         };
         // ---- pts_linears.0 : PE(64) -> 256
@@ -340,13 +347,28 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
             o.w = sigma;
             *reinterpret_cast<f32x4*>(a.raw + P * 4) = o;
         }
+        DIAG_ONLY(dg.acc[kDgTotal] += clock64() - t_tile;)
         cur = nxt;
     }
+#ifdef IDN_DIAG   // diagnostic build only: per-wave cycle totals by category (tools/diag_mlp_x6.py)
+    if (lane == 0)
+        for (int c = 0; c < 5; ++c) atomicAdd(&g_diag[c], dg.acc[c]);
+    if (lane == 0) atomicAdd(&g_diag[5], 1ull);
+#endif
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 }
 
 }  // namespace x6
+
+#ifdef IDN_DIAG
+extern "C" int idealnerf_diag_read_x6(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof(z)) != hipSuccess) return -3;
+    return 0;
+}
+#endif
 
 int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, const float* rays, const float* z,
                       const float* pts, const float* dirs, int64_t n_points, int n_samples, float* raw, hipStream_t s,
