@@ -40,6 +40,7 @@ def mode_peaks():
     mixed_peak = 1.0 / (0.25 / PEAK_F32_MFMA_TFLOPS + 0.75 / (PEAK_BF16_MFMA_TFLOPS / 3.0))
     return {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3.0,
             "bf16": PEAK_BF16_MFMA_TFLOPS, "mixed": mixed_peak,   # the dense fp16 and bf16 MFMA peaks are equal on gfx950
+            "mixed6": 1.0 / (0.25 / (PEAK_BF16_MFMA_TFLOPS / 6.0) + 0.75 / (PEAK_BF16_MFMA_TFLOPS / 3.0)),   # bf16x6 coarse + bf16x3 fine
             "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0}                # six bf16 piece products per algorithmic product
 
 
@@ -473,7 +474,7 @@ def main():
     ap.add_argument("--soak", action="store_true",
                     help="compare every timed frame with the first one bit for bit (the path is deterministic: a mismatch is "
                          "a race); reported as `soak_mismatched_frames`")
-    ap.add_argument("--precision", choices=["f32", "mixed", "fp16x3", "bf16x3", "bf16", "bf16x6"], default=os.environ.get("IDN_PRECISION", "f32"),
+    ap.add_argument("--precision", choices=["f32", "mixed", "mixed6", "fp16x3", "bf16x3", "bf16", "bf16x6"], default=os.environ.get("IDN_PRECISION", "f32"),
                     help="arithmetic of the MLP contraction.  f32 (default, the headline line): exact fp32 MFMA chains, "
                          "RGB within 1e-6..1e-5 of the reference.  bf16x3: three bf16 MFMAs per product, 3.4x faster, "
                          "within the 1e-4 RGB budget on the reference's golden frame and this scene, but sharp scenes "
@@ -523,7 +524,7 @@ def main():
     bc = syn["bc"][r0:r1].reshape(-1, 3).contiguous().to(dev)
     t_vals, u = linspace01(S, dev), linspace01(Ni, dev)
     def set_mode(mode):
-        coarse.precision, fine.precision = ("f32", "bf16x3") if mode == "mixed" else (mode, mode)
+        coarse.precision, fine.precision = {"mixed": ("f32", "bf16x3"), "mixed6": ("bf16x6", "bf16x3")}.get(mode, (mode, mode))
     set_mode(args.precision)
     pk_c, pk_f = coarse.packed_weights(), fine.packed_weights()
     prec, prec_f = coarse.prec_code, fine.prec_code
@@ -583,12 +584,13 @@ def main():
                  "bf16": "idn::mlp_bf16_kernel<kModeRays> (fused PE + FaceNeRF MLP, plain bf16 MFMA)",
                  "fp16x3": "idn::mlp_fp16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 fp16 MFMAs per product)",
                  "mixed": "idn::mlp_f32_kernel (coarse network) + idn::mlp_bf16x3_kernel (fine network); blended peak",
+                 "mixed6": "idn::x6::mlp_bf16x6_kernel (coarse network) + idn::mlp_bf16x3_kernel (fine network); blended peak",
                  "bf16x6": "idn::x6::mlp_bf16x6_kernel<kModeRays> (fused PE + FaceNeRF MLP, 6 bf16 piece products per fp32 product)"}[args.precision]
         res = {
             "metric": "ray-samples/sec (64+128 pts, 512x512), whole job", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "ranks": world, "backend": backend,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)", "mixed": "f32 coarse network + bf16x3 fine network", "fp16x3": "fp16x3 (fp32 in/out, fp32 accumulate)", "bf16x6": "bf16x6 (operands as three bf16 pieces = 24 significand bits, fp32 accumulate: fp32-grade)"}[args.precision], "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)", "mixed": "f32 coarse network + bf16x3 fine network", "mixed6": "bf16x6 (fp32-grade) coarse network + bf16x3 fine network", "fp16x3": "fp16x3 (fp32 in/out, fp32 accumulate)", "bf16x6": "bf16x6 (operands as three bf16 pieces = 24 significand bits, fp32 accumulate: fp32-grade)"}[args.precision], "data": "synthetic",
             "per_gpu": value / world, "rays_per_s": value / (S + S + Ni),
             **({"soak_mismatched_frames": int(mismatched.item())} if args.soak else {}),
             "config": {"workload": f"BASELINE configs[1]: May HeadNeRF {H}x{W} full-frame render, N_sample=64 "
@@ -617,7 +619,9 @@ def main():
                                "fp32 accumulate; priced against the fp16 (= bf16) peak / 3")
             notes["bf16x6"] = ("IDN_PREC_BF16X6: weights and activations as the exact sum of three bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per "
                                "product, fp32 accumulate: fp32-grade (<= 2^-23 per product), fp32's range; priced against bf16 peak / 6")
-            for other in (["bf16x6", "fp16x3", "mixed", "bf16x3"] if args.precision == "f32" else ["f32"]):
+            notes["mixed6"] = ("coarse network (drives the importance sampling) in bf16x6 -- fp32-grade on the bf16 pipe --, fine network in "
+                               "bf16x3; priced against the blended peak of the two kernels")
+            for other in (["bf16x6", "mixed6", "fp16x3", "mixed", "bf16x3"] if args.precision == "f32" else ["f32"]):
                 set_mode(other)
                 pko_c, pko_f = coarse.packed_weights(), fine.packed_weights()
                 code_c, code_f = coarse.prec_code, fine.prec_code
