@@ -137,7 +137,7 @@ struct RecordSide {
 };
 // A 256 x 256 layer's tile is exactly one slice of the stream (16 k-steps x 4 fragments), and a wave issues its pieces of
 // the next slice in the FIRST half of a slice.  Tile t - 1 is therefore recorded in the SECOND half of tile t (sign bits
-// and ReLU at step 7, one row store at each of steps 8..11): those four stores are younger than the pieces the barrier at
+// and ReLU at step 7, one row store at each of steps 8, 10, 12, 14): those four stores are younger than the pieces the barrier at
 // the end of the tile waits for, and vmcnt retires in issue order, so that barrier waits `vmcnt(4)` and the stores get
 // the next one and a half slices to reach memory, spread over the layer instead of one burst of 32 at its end.
 struct RecordInShadow : RecordSide {
@@ -145,7 +145,9 @@ struct RecordInShadow : RecordSide {
     __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {
         if constexpr (T > 0) {
             if constexpr (S == 7) signs_relu(ic<T - 1>{});
-            if constexpr (S >= 8 && S < 12) store1(ic<T - 1>{}, ic<S - 8>{});
+            // one store at each of steps 8, 10, 12, 14: the four waves of a CU run in lockstep, and 4 KiB of stores per k-step
+            // is twice what the chip's write path takes from a CU (at 8, 9, 10, 11: forward 4.73 -> 4.63 ms)
+            if constexpr (S >= 8 && S < 16 && (S & 1) == 0) store1(ic<T - 1>{}, ic<(S - 8) / 2>{});
         }
     }
 };

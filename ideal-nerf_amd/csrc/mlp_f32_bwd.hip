@@ -503,14 +503,14 @@ struct MaskStoreSide {
         *reinterpret_cast<f32x4*>(row + 32 * T + 8 * Q) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
     }
     // A trunk stage's tile is exactly one slice of the stream, and a wave issues its pieces of the next slice in the FIRST
-    // half of a slice: tile t - 1 is masked at step 7 of tile t and written at steps 8..11 -- four stores younger than the
+    // half of a slice: tile t - 1 is masked at step 7 of tile t and written at steps 8, 10, 12, 14 -- four stores younger than the
     // pieces the barrier at the end of the tile waits for (`vmcnt(4)` there: vmcnt retires in issue order), with one and a
     // half slices to reach memory, instead of a burst of 32 at the end of the stage.  Other stages: after the stage.
     template <int T, int S>
     __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {
         if constexpr (KS == 16 && T > 0) {
             if constexpr (S == 7) apply(ic<T - 1>{});
-            if constexpr (S >= 8 && S < 12) store1(ic<T - 1>{}, ic<S - 8>{});
+            if constexpr (S >= 8 && S < 16 && (S & 1) == 0) store1(ic<T - 1>{}, ic<(S - 8) / 2>{});   // steps 8, 10, 12, 14
         }
     }
 };
