@@ -359,7 +359,7 @@ def bench_torso(args):
     prec = args.precision if args.precision_given else "bf16"
     syn = synthetic.frame(H, W, seed=rank)   # every rank renders a different frame of the clip
     cfg = RenderConfig(perturb=0.0, chunk=32768, near=syn["near"], far=syn["far"], dim_expr=76)
-    net = Network(H, W, syn["focal"], syn["near"], syn["far"], 32768, None, 64, 128, args=cfg, dim_expr_head=76).to(dev).eval()
+    net = Network(H, W, syn["focal"], syn["near"], syn["far"], 32768, 64, 128, args=cfg, dim_expr_head=76).to(dev).eval()
     for i, m in enumerate((net.face_nerf_coarse, net.face_nerf_fine, net.torso_coarse_nerf, net.torso_fine_nerf)):
         synthetic.xavier_state_dict(m, 2 + i, 300.0 if i < 2 else 4.0, 0.3 if i < 2 else -0.2)
     idealnerf_amd.set_render_precision(net, prec)   # "mixed" = fp32 coarse + bf16x3 fine network of each pair

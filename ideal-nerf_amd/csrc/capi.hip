@@ -93,7 +93,7 @@ size_t idealnerf_packed_weight_floats(int precision) {
     // 4 bytes per weight (fp32, or bf16 hi + bf16 lo); 2 for the plain-bf16 stream
     if (precision == IDN_PREC_F32 || precision == IDN_PREC_BF16X3 || precision == IDN_PREC_FP16X3) return (size_t)kStreamFrags * kFragFloats;
     if (precision == IDN_PREC_BF16) return (size_t)kPlainStreamFrags * kFragFloats;
-    if (precision == IDN_PREC_BF16X6) return (size_t)kX6StreamFrags * kFragFloats;   // three bf16 pieces (+ a zero fragment) per weight
+    if (precision == IDN_PREC_BF16X6) return (size_t)kX6StreamFrags * kFragFloats;   // three bf16 pieces per weight, 48-fragment slices
     return 0;
 }
 size_t idealnerf_folded_bias_floats(void) { return kBiasFloats; }

@@ -71,11 +71,18 @@ constexpr int kPlainNumSlices =
 constexpr int kPlainStreamFrags = kPlainNumSlices * kSliceFrags;                   // 1152
 static_assert(kPlainUsedFrags == 1122 && kPlainUsedFrags % 2 == 0, "plain stream table changed");
 
-// Six-piece bf16 stream (IDN_PREC_BF16X6): per (n-tile, 16-channel k-step) a quad of fragments (p1, p2, p3, zero) --
-// the three bf16 pieces of each weight -- i.e. twice the fragments of the streams above, layer by layer.
-constexpr int kX6UsedFrags = 2 * kUsedFrags;       // 4488
-constexpr int kX6NumSlices = 2 * kNumSlices;       // 72
-constexpr int kX6StreamFrags = 2 * kStreamFrags;   // 4608
+// Six-piece bf16 stream (IDN_PREC_BF16X6): per (n-tile, 16-channel k-step) a TRIPLE of fragments (p1, p2, p3) -- the three
+// bf16 pieces of each weight.  Its ring slots hold 48 fragments = 16 k-steps, so slices, layer starts and ring phases sit on
+// the same k-steps as in the 64-fragment rings above (16 k-steps of two fragments), and the stream is 3.375 MiB: it stays
+// in a 4 MiB per-XCD L2.  (Round 2 padded every triple to a quad with a zero fragment: 4.5 MiB, 5 GB of fabric reads per
+// launch where the other streams cause 43 MB.)
+constexpr int kX6KFrags = 3;                                   // fragments per k-step
+constexpr int kX6SliceFrags = 16 * kX6KFrags;                  // 48: one ring slot = 16 k-steps = 48 KiB
+constexpr int kX6RingFrags = kRingSlots * kX6SliceFrags;       // 96 KiB ring
+constexpr int kX6UsedFrags = kX6KFrags * kPlainUsedFrags;      // 3366
+constexpr int kX6NumSlices = 2 * kNumSlices;                   // 72 (the same k-steps per slice as a quad stream had)
+constexpr int kX6StreamFrags = kX6NumSlices * kX6SliceFrags;   // 3456 = 3.375 MiB
+static_assert(kX6UsedFrags <= kX6StreamFrags && kX6StreamFrags - kX6UsedFrags < kX6RingFrags + kX6SliceFrags, "x6 stream table");
 
 // Folded bias block: one float per output channel, natural channel order
 // (accumulator register 4q+j of tile t, lane half h <-> channel 32 t + 8 q + 4 h + j).

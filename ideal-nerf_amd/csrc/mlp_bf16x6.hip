@@ -15,14 +15,15 @@
 // which the finished layer no longer needs.  (Input and output both as pieces -- the bf16x3 kernel's two ping-pong
 // sets -- would be 384 registers before accumulators and encodings.)
 //
-// Weight stream: per (n-tile, 16-channel k-step) a QUAD of fragments (p1, p2, p3, zero): twice the fragments of the
-// bf16x3 stream, so every layer starts where it does there modulo the ring, and slices hold whole quads.
+// Weight stream: per (n-tile, 16-channel k-step) a TRIPLE of fragments (p1, p2, p3) in 48-fragment ring slots: a slice is
+// 16 k-steps, as in the bf16x3 stream (16 pairs), so every layer starts where it does there modulo the ring, slices hold
+// whole triples, and the 3.375 MiB stream stays in the per-XCD L2 (idn_internal.h).
 #include "mlp_x6.h"
 
 namespace idn {
 namespace x6 {
 
-constexpr int f0(int l) { return 2 * layer_f0(l); }   // quads: 4 fragments per k-step where layer_f0 counts 2
+constexpr int f0(int l) { return kX6KFrags * plain_f0(l); }   // triples: 3 fragments per k-step (plain_f0 counts k-steps)
 
 // One layer, tile-major: for each n-tile t, KS k-steps of six piece products into O[t].  bget(ic<q>, ic<s>) =
 // piece q of k-step s of the layer's input.  The first fragments arrive in `pref` (issued by the layer before, or
@@ -33,16 +34,16 @@ struct NoTileSide {
     __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {}
 };
 template <int F0, int NT, int KS, int OPEN_YOUNGER = 0, int MID_YOUNGER = 0, class BGet, class Side = NoTileSide, class Hook = NoHook>
-__device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGet&& bget, WStream& ws, FragReader& fr,
+__device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGet&& bget, WStream6& ws, FragReader& fr,
                                           f32x4 (&pref)[3], Side&& side = NoTileSide{}, Hook&& after_open = NoHook{}) {
     constexpr int NP = NT * KS;
-    constexpr bool LAST = (F0 + 4 * NP == kX6UsedFrags);
-    static_assert(F0 % 4 == 0 && KS >= 4, "quads; the next tile's bias rides on the first four k-steps");
+    constexpr bool LAST = (F0 + kX6KFrags * NP == kX6UsedFrags);
+    static_assert(F0 % kX6KFrags == 0 && KS >= 4, "triples; the next tile's bias rides on the first four k-steps");
     bias_tile(O[0], bias_half);
-    if constexpr (F0 % kSliceFrags == 0) {
+    if constexpr (F0 % kX6SliceFrags == 0) {
         ws.template open_slice<OPEN_YOUNGER>();   // (training: the row stores of the layer before stay in flight)
         after_open();
-        static_for<3>([&](auto Q) { pref[decltype(Q)::value] = fr.template issue<F0 + decltype(Q)::value>(); });
+        static_for<3>([&](auto Q) { pref[decltype(Q)::value] = issue6<F0 + decltype(Q)::value>(fr); });
         retire3<0>(pref);
     } else {
         static_assert(std::is_same_v<std::decay_t<Hook>, NoHook>, "a hook needs a layer that starts on a slice boundary");
@@ -51,18 +52,17 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
     static_for<NP>([&](auto PI) {
         constexpr int pi = decltype(PI)::value;
         constexpr int t = pi / KS, s = pi % KS;
-        constexpr int f = F0 + 4 * pi;
-        constexpr bool next_crosses = ((f + 4) % kSliceFrags == 0);
+        constexpr int f = F0 + kX6KFrags * pi;
+        constexpr bool next_crosses = ((f + kX6KFrags) % kX6SliceFrags == 0);
         constexpr bool has_next = !(LAST && pi + 1 == NP);
         f32x4 n[3] = {a[0], a[1], a[2]};
         if constexpr (!next_crosses && has_next) {
-            static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value>(fr); });
             if constexpr (pi > 0) retire3<3>(a);   // (step 0's arrived retired)
         } else {
             if constexpr (pi > 0) retire3<0>(a);
         }
-        ws.template step_piece<f>();
-        ws.template step_piece<f + 2>();
+        step_pieces6<f>(ws);
         const f32x4 b1 = bget(ic<0>{}, ic<s>{}), b2 = bget(ic<1>{}, ic<s>{}), b3 = bget(ic<2>{}, ic<s>{});
         O[t] = mfma_bf(a[0], b1, O[t]);   // w1 a1
         O[t] = mfma_bf(a[0], b2, O[t]);   // w1 a2
@@ -76,14 +76,14 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
             // MID_YOUNGER (training, layers whose tiles are slices): the row stores issued in the second half of the slice
             // that ends here -- none in tile 0 -- are younger than the pieces of the slice being opened
             ws.template open_slice<(t >= 1 ? MID_YOUNGER : 0)>();
-            static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value>(fr); });
         }
         a[0] = n[0];
         a[1] = n[1];
         a[2] = n[2];
     });
     // hand over retired fragments (those of the next layer's first k-step, when this layer ends inside a slice)
-    if constexpr (!LAST && (F0 + 4 * NP) % kSliceFrags != 0) retire3<0>(a);
+    if constexpr (!LAST && (F0 + kX6KFrags * NP) % kX6SliceFrags != 0) retire3<0>(a);
     pref[0] = a[0];
     pref[1] = a[1];
     pref[2] = a[2];
@@ -135,8 +135,8 @@ struct RecordSide {
         *reinterpret_cast<f32x4*>(row + 32 * T + 8 * Q) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
     }
 };
-// A 256 x 256 layer's tile is exactly one slice of the stream (16 k-steps x 4 fragments), and a wave issues its pieces of
-// the next slice in the FIRST half of a slice.  Tile t - 1 is therefore recorded in the SECOND half of tile t (sign bits
+// A 256 x 256 layer's tile is exactly one slice of the stream (16 k-steps x 3 fragments), and a wave issues its pieces of
+// the next slice in the FIRST half of a slice (two at each of k-steps 0..5).  Tile t - 1 is therefore recorded in the SECOND half of tile t (sign bits
 // and ReLU at step 7, one row store at each of steps 8, 10, 12, 14): those four stores are younger than the pieces the barrier at
 // the end of the tile waits for, and vmcnt retires in issue order, so that barrier waits `vmcnt(4)` and the stores get
 // the next one and a half slices to reach memory, spread over the layer instead of one burst of 32 at its end.
@@ -163,7 +163,7 @@ template <int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
-    float* bias_s = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes);
+    float* bias_s = reinterpret_cast<float*>(smem + kX6RingFrags * kFragBytes);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -174,9 +174,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
     __syncthreads();  // the bias block is read (by other waves) before the first slice barrier
 
     Diag dg;
-    WStream ws;
+    WStream6 ws;
     ws.dg = &dg;
-#ifdef IDN_TIMING_STREAM_WRAP   // timing-only (wrong results): the stream wraps after this many slices -- does the 4.5 MiB stream miss L2?
+#ifdef IDN_TIMING_STREAM_WRAP   // timing-only (wrong results): the stream wraps after this many slices -- is anything left of the L2 question?
     ws.init(a.wstream, IDN_TIMING_STREAM_WRAP, ring, tid, wave);
 #else
     ws.init(a.wstream, kX6NumSlices, ring, tid, wave);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
         constexpr int kOpenYounger = IDN_TEST_OPEN_YOUNGER, kMidYounger = IDN_TEST_MID_YOUNGER;
         auto layer = [&](auto F0c, auto NTc, auto KSc, auto LDc, const float* bias_l, auto&& bget, int idx, auto&& hook) __attribute__((always_inline)) {
             constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KS = decltype(KSc)::value, LD = decltype(LDc)::value;
-            constexpr bool tile_is_slice = NT == 8 && KS == 16 && F0 % kSliceFrags == 0;
+            constexpr bool tile_is_slice = NT == 8 && KS == 16 && F0 % kX6SliceFrags == 0;
             if constexpr (SAVE) {
                 float* row = a.acts + (long)act_off(idx) * a.p_pad + P * LD + 4 * h;
                 if constexpr (tile_is_slice) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
         layer(ic<f0(10)>{}, ic<4>{}, ic<8>{}, ic<128>{}, bias_h + bias_off(10), tiles, kActV1 + 2, NoHook{});
         // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile)
         run_layer<f0(11), 1, 8>(O, bias_h + bias_off(11), tiles, ws, fr, pref);
-        finish_pass<kX6UsedFrags, kX6StreamFrags>(ws);
+        finish_pass6<kX6UsedFrags, kX6StreamFrags>(ws);
 
         if (valid && h == 0) {
             f32x4 o;
@@ -381,13 +381,13 @@ int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, 
     int num_cu = 0;
     if (int e = setup.get([]() -> int {
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeRays, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, x6::kMlpLds6));
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeRays, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, x6::kMlpLds6));
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeX, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, x6::kMlpLds6));
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModePts, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, x6::kMlpLds6));
             return IDN_OK;
         }, &num_cu))
         return e;
@@ -396,13 +396,13 @@ int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, 
     MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, acts, (long)p_pad};
     ProfScope prof(s, n_points, acts ? IDN_PROF_MLP_FWD_SAVE_X6 : IDN_PROF_MLP_FWD);
     if (x)
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeX, false>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeX, false>), dim3(grid), dim3(256), x6::kMlpLds6, s, a);
     else if (pts)
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModePts, false>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModePts, false>), dim3(grid), dim3(256), x6::kMlpLds6, s, a);
     else if (acts)
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, true>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, true>), dim3(grid), dim3(256), x6::kMlpLds6, s, a);
     else
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, false>), dim3(grid), dim3(256), kMlpLds, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, false>), dim3(grid), dim3(256), x6::kMlpLds6, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

@@ -70,11 +70,14 @@ struct Diag {};
 // ---------------------------------------------------------------------------
 constexpr int kAhead = kRingSlots - 1;  // slices in flight ahead of the consumer
 
-template <int NW>
+template <int NW, int SLICE_FRAGS = kSliceFrags>
 struct WStreamT {
+    static constexpr int kSliceFragsT = SLICE_FRAGS;               // fragments per ring slot (64; the six-piece streams: 48)
+    static constexpr int kSliceBytesT = SLICE_FRAGS * kFragBytes;
     static constexpr int kPieceBytes = NW * kFragBytes;
-    static constexpr int kPieces = kSliceBytes / kPieceBytes;     // pieces per slice
+    static constexpr int kPieces = kSliceBytesT / kPieceBytes;     // pieces per slice
     static constexpr int kVmcntOpen = (kAhead - 1) * kPieces;      // younger pieces allowed in flight at a barrier
+    static_assert(kSliceBytesT % kPieceBytes == 0 && kPieces % 4 == 0, "a wave's pieces come in groups of four (one M0 / scalar offset per group)");
     static_assert(kVmcntOpen == 0 || kVmcntOpen == 8 || kVmcntOpen == 16, "add the s_waitcnt literal below");
 
     Diag* dg;
@@ -86,7 +89,7 @@ struct WStreamT {
     char* ring_wave;    // ring + this wave's block of a slice (wave-uniform LDS destination base)
 
     __device__ __forceinline__ void init(const float* stream, int slices, char* ring, int tid, int wave) {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, slices * kSliceBytes, 0x00020000);  // raw, untyped
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, slices * kSliceBytesT, 0x00020000);  // raw, untyped
         // wave w fetches the kPieces consecutive fragments w * kPieces .. of every slice: four consecutive
         // pieces then differ only in the instruction's immediate offset (1 KiB steps, applied to the global
         // and the LDS address alike), so a slot needs kPieces / 4 M0 / scalar-offset values instead of
@@ -99,7 +102,7 @@ struct WStreamT {
         static_for<kAhead>([&](auto S_) { issue_rest<decltype(S_)::value, 0>(); });  // slices 0 .. kAhead-1
     }
     __device__ __forceinline__ void advance() {
-        soff += kSliceBytes;
+        soff += kSliceBytesT;
         if (++next_slice == num_slices) {
             next_slice = 0;
             soff = 0;
@@ -107,7 +110,7 @@ struct WStreamT {
     }
     template <int SLOT, int J>
     __device__ __forceinline__ void issue_piece() {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(ring_wave + SLOT * kSliceBytes + (J / 4) * (4 * kFragBytes)), 16, voff,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(ring_wave + SLOT * kSliceBytesT + (J / 4) * (4 * kFragBytes)), 16, voff,
                                                  soff + (J / 4) * (4 * kFragBytes), (J % 4) * kFragBytes, 0);
         if constexpr (J == kPieces - 1) advance();
     }
@@ -135,9 +138,15 @@ struct WStreamT {
     // the piece (if any) to issue at the pair-step that consumes fragment F
     template <int F>
     __device__ __forceinline__ void step_piece() {
-        constexpr int jpos = (F % kSliceFrags) / 2;
-        constexpr int slot = (F / kSliceFrags + kAhead) % kRingSlots;
+        constexpr int jpos = (F % SLICE_FRAGS) / 2;
+        constexpr int slot = (F / SLICE_FRAGS + kAhead) % kRingSlots;
         if constexpr (jpos < kPieces) issue_piece<slot, jpos>();
+    }
+    // the same by position: piece JPOS (if the slice has that many) of the slice fetched while slice F / SLICE_FRAGS is consumed
+    template <int F, int JPOS>
+    __device__ __forceinline__ void step_piece_at() {
+        constexpr int slot = (F / SLICE_FRAGS + kAhead) % kRingSlots;
+        if constexpr (JPOS < kPieces) issue_piece<slot, JPOS>();
     }
 };
 using WStream = WStreamT<4>;
@@ -155,9 +164,9 @@ struct FragReader {
     uint32_t addr0, addr1;  // LDS byte address of this lane's 16 bytes in fragment 0 / fragment 64
     f32x4 pref0, pref1;     // fragment pair issued ahead of its consumer (layer / slice start)
 
-    template <int F>
+    template <int F, int RING_FRAGS = kRingFrags>
     __device__ __forceinline__ f32x4 issue() const {
-        constexpr int fr = F % kRingFrags;
+        constexpr int fr = F % RING_FRAGS;
         f32x4 v;
         if constexpr (fr < 64)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr0), "n"(fr * kFragBytes) : "memory");

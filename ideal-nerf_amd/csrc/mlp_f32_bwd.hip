@@ -345,25 +345,26 @@ int launch_delta_chain(const float* packed_bwd, const float* acts, int64_t p_pad
 // (192 registers for 256 channels x 32 points), its output as the fp32 accumulator tiles; at the end of a stage
 // the accumulators are masked, written to the delta matrix (this lane's row: a quad of registers is 16 contiguous
 // bytes of it) and split into the piece registers, which the finished stage no longer needs.
-// Stream: per (tile, 16-channel k-step) a quad of fragments (p1, p2, p3, zero) = twice the fp32 stream's fragments,
-// stage by stage, so every stage keeps its ring phase.
+// Stream: per (tile, 16-channel k-step) a triple of fragments (p1, p2, p3) in 48-fragment ring slots (idn_internal.h,
+// mlp_x6.h): a slice is 16 k-steps as in the fp32 stream (16 pairs), so every stage keeps its ring phase; 3.19 MiB.
 // ===========================================================================================
-constexpr int kBwd6StreamFrags = 2 * kBwdStreamFrags;   // 4352
-constexpr int kBwd6NumSlices = 2 * kBwdNumSlices;       // 68
-constexpr int bwd6_f0(int s) { return 2 * bwd_f0(s); }
+constexpr int bwd6_f0(int s) { return kX6KFrags * (bwd_f0(s) / 2); }   // bwd_f0 counts two fragments per k-step
+constexpr int kBwd6StreamFrags = kX6KFrags * (kBwdStreamFrags / 2);    // 3264
+constexpr int kBwd6NumSlices = kBwd6StreamFrags / kX6SliceFrags;       // 68
+static_assert(kBwd6StreamFrags % kX6SliceFrags == 0 && kBwd6NumSlices % kRingSlots == 0 && bwd6_f0(4) % kX6RingFrags == 0, "ring phase of the trunk stages");
 
 __global__ void pack_bf16x6_bwd_kernel(BwdPackDesc d, uint4* out) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= kBwd6StreamFrags * 64) return;
-    const int f = gid >> 6, lane = gid & 63, part = f & 3;
+    const int f = gid >> 6, lane = gid & 63, part = f % kX6KFrags;
     unsigned w[4] = {0u, 0u, 0u, 0u};
     int s = -1;
     for (int i = 0; i < kBwdStages; ++i)
-        if (f >= bwd6_f0(i) && f < bwd6_f0(i) + 2 * kBwdNT[i] * kBwdKG[i]) s = i;
-    if (s >= 0 && part < 3) {
+        if (f >= bwd6_f0(i) && f < bwd6_f0(i) + kX6KFrags * kBwdNT[i] * (kBwdKG[i] / 2)) s = i;
+    if (s >= 0) {
         const BwdPackStage& S = d.st[s];
         const int ksn = kBwdKG[s] / 2;
-        const int rel = (f - bwd6_f0(s)) >> 2, t = rel / ksn, ks = rel - t * ksn;
+        const int rel = (f - bwd6_f0(s)) / kX6KFrags, t = rel / ksn, ks = rel - t * ksn;
         const int n = 32 * t + (lane & 31), h = lane >> 5;
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * ks + (j & 3) + 8 * (j >> 2) + 4 * h;   // the element order an accumulator tile splits into
@@ -403,34 +404,33 @@ namespace x6 {
 // One stage's MFMAs: zeroed accumulators, KS k-steps of six piece products per tile (run_layer of mlp_bf16x6.hip
 // without the bias).  LAST: nothing is read ahead past this stage (the padding before the trunk / the end of the pass).
 template <int F0, int NT, int KS, bool LAST, int OPEN_YOUNGER, int MID_YOUNGER, class BGet, class Side>
-__device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, FragReader& fr, f32x4 (&pref)[3], Side&& side) {
+__device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream6& ws, FragReader& fr, f32x4 (&pref)[3], Side&& side) {
     constexpr int NP = NT * KS;
-    static_assert(F0 % 4 == 0, "quads");
+    static_assert(F0 % kX6KFrags == 0, "triples");
     static_for<NT>([&](auto T) { static_for<16>([&](auto R) { O[decltype(T)::value][decltype(R)::value] = 0.0f; }); });
-    if constexpr (F0 % kSliceFrags == 0) {
+    if constexpr (F0 % kX6SliceFrags == 0) {
         // OPEN_YOUNGER: the stage before this one has issued that many row stores after this wave's last piece of the slice
         // being opened: they stay in flight.  (Never more than were issued: the count must not reach back into the pieces --
         // tools/audit_asm_loads.py counts them on every path.)
         ws.template open_slice<OPEN_YOUNGER>();
-        static_for<3>([&](auto Q) { pref[decltype(Q)::value] = fr.template issue<F0 + decltype(Q)::value>(); });
+        static_for<3>([&](auto Q) { pref[decltype(Q)::value] = issue6<F0 + decltype(Q)::value>(fr); });
         retire3<0>(pref);
     }
     f32x4 a[3] = {pref[0], pref[1], pref[2]};
     static_for<NP>([&](auto PI) {
         constexpr int pi = decltype(PI)::value;
         constexpr int t = pi / KS, s = pi % KS;
-        constexpr int f = F0 + 4 * pi;
-        constexpr bool next_crosses = ((f + 4) % kSliceFrags == 0);
+        constexpr int f = F0 + kX6KFrags * pi;
+        constexpr bool next_crosses = ((f + kX6KFrags) % kX6SliceFrags == 0);
         constexpr bool has_next = !(LAST && pi + 1 == NP);
         f32x4 n[3] = {a[0], a[1], a[2]};
         if constexpr (!next_crosses && has_next) {
-            static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value>(fr); });
             if constexpr (pi > 0) retire3<3>(a);   // (step 0's arrived retired)
         } else {
             if constexpr (pi > 0) retire3<0>(a);
         }
-        ws.template step_piece<f>();
-        ws.template step_piece<f + 2>();
+        step_pieces6<f>(ws);
         const f32x4 b1 = bget(ic<0>{}, ic<s>{}), b2 = bget(ic<1>{}, ic<s>{}), b3 = bget(ic<2>{}, ic<s>{});
         O[t] = mfma_bf(a[0], b1, O[t]);
         O[t] = mfma_bf(a[0], b2, O[t]);
@@ -443,13 +443,13 @@ __device__ __forceinline__ void run_stage6(f32x16* O, BGet&& bget, WStream& ws, 
             // MID_YOUNGER (trunk stages, whose tiles are slices): the row stores issued in the second half of the slice that
             // ends here -- none in tile 0 -- are younger than the pieces of the slice being opened
             ws.template open_slice<(t >= 1 ? MID_YOUNGER : 0)>();
-            static_for<3>([&](auto Q) { n[decltype(Q)::value] = fr.template issue<f + 4 + decltype(Q)::value>(); });
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value>(fr); });
         }
         a[0] = n[0];
         a[1] = n[1];
         a[2] = n[2];
     });
-    if constexpr (!LAST && (F0 + 4 * NP) % kSliceFrags != 0) retire3<0>(a);   // hand over retired fragments
+    if constexpr (!LAST && (F0 + kX6KFrags * NP) % kX6SliceFrags != 0) retire3<0>(a);   // hand over retired fragments
     pref[0] = a[0];
     pref[1] = a[1];
     pref[2] = a[2];
@@ -515,7 +515,7 @@ struct MaskStoreSide {
     }
 };
 
-constexpr int kDelta6Lds = kRingFrags * kFragBytes;
+constexpr int kDelta6Lds = kX6RingFrags * kFragBytes;
 
 __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
     const int m = lane & 31, h = lane >> 5;
 
     Diag dg;
-    WStream ws;
+    WStream6 ws;
     ws.dg = &dg;
     ws.init(a.wstream, kBwd6NumSlices, ring, tid, wave);
     FragReader fr;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
                       else return in_sig[q];
                   },
                   6, a.da[7]);
-        finish_pass<2 * kBwdHeadFrags, 2 * kBwdTrunk0>(ws);   // walk the padding up to the trunk stages
+        finish_pass6<kX6KFrags * (kBwdHeadFrags / 2), bwd6_f0(4)>(ws);   // walk the padding up to the trunk stages
         // 4: pts_linears.7^T follows the padding walk, not a stage: its first slice is opened with a full wait.
         // 5..9: pts_linears.6 .. .2 ^T, one code instance (a trunk stage is four ring lengths), each opening its first slice
         // behind the 8 row stores of tiles 6 and 7 of the stage before it; then pts_linears.1^T.

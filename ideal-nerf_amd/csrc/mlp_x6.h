@@ -52,6 +52,36 @@ __device__ __forceinline__ void convert_tile(const f32x16& acc, PTile6& out) {
     });
 }
 
+// The six-piece streams: 48-fragment ring slots (16 k-steps of three fragments), 12 LDS-DMA pieces per wave and slice.
+using WStream6 = WStreamT<4, kX6SliceFrags>;
+static_assert(WStream6::kPieces == 12, "two pieces at each of the first six k-steps of a slice");
+// fragment Q of the k-step at stream fragment F (F a multiple of 3)
+template <int F>
+__device__ __forceinline__ f32x4 issue6(const FragReader& fr) {
+    return fr.template issue<F, kX6RingFrags>();
+}
+// the pieces (if any) issued at the k-step that starts at fragment F: two per k-step, so a wave's twelve pieces of the
+// next slice are all issued in the first six k-steps of a slice (before anything the training variants store in its
+// second half: those stores stay YOUNGER than the pieces)
+template <int F>
+__device__ __forceinline__ void step_pieces6(WStream6& ws) {
+    static_assert(F % kX6KFrags == 0, "k-steps");
+    constexpr int ks = (F % kX6SliceFrags) / kX6KFrags;
+    ws.template step_piece_at<F, 2 * ks>();
+    ws.template step_piece_at<F, 2 * ks + 1>();
+}
+// End of a pass: walk the unused tail of the stream k-step by k-step without reading it (finish_pass of mlp_common.h).
+template <int F_END, int STREAM_FRAGS>
+__device__ __forceinline__ void finish_pass6(WStream6& ws) {
+    static_assert(F_END % kX6KFrags == 0 && STREAM_FRAGS % kX6SliceFrags == 0, "k-steps; whole slices");
+    static_for<(STREAM_FRAGS - F_END) / kX6KFrags>([&](auto I) {
+        constexpr int f = F_END + kX6KFrags * decltype(I)::value;
+        if constexpr (f % kX6SliceFrags == 0) ws.open_slice();
+        step_pieces6<f>(ws);
+    });
+}
+constexpr int kMlpLds6 = kX6RingFrags * kFragBytes + kBiasFloats * 4;
+
 // all but the newest `Newer` LDS reads of this wave have completed => the three fragments are valid
 template <int Newer>
 __device__ __forceinline__ void retire3(f32x4 (&v)[3]) {

@@ -95,19 +95,19 @@ __global__ void pack_bf16x3_kernel(PackDesc d, uint4* out, int fmt) {
     out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// six-piece stream: fragment quad (4p .. 4p+3) of a tile = pieces p1, p2, p3 of one 16-channel k-step and a zero
-// fragment; same lane / element order as the bf16x3 stream.  p1 = bf16(w), p2 = bf16(w - p1), p3 = bf16(w - p1 - p2).
+// six-piece stream: fragment triple (3p .. 3p+2) of a tile = pieces p1, p2, p3 of one 16-channel k-step; same lane /
+// element order as the bf16x3 stream.  p1 = bf16(w), p2 = bf16(w - p1), p3 = bf16(w - p1 - p2).
 __global__ void pack_bf16x6_kernel(PackDesc d, uint4* out) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= kX6StreamFrags * 64) return;
     const int f = gid >> 6, lane = gid & 63;
     unsigned w[4] = {0u, 0u, 0u, 0u};
-    const int part = f & 3;
-    if (f < kX6UsedFrags && part < 3) {
+    const int part = f % kX6KFrags;
+    if (f < kX6UsedFrags) {
         int l = 0;
-        while (l + 1 < kNumLayers && f >= 2 * d.L[l + 1].f0) ++l;
+        while (l + 1 < kNumLayers && f >= kX6KFrags * (d.L[l + 1].f0 / 2)) ++l;   // L.f0 counts two fragments per k-step
         const PackLayer& L = d.L[l];
-        const int rel = (f - 2 * L.f0) >> 2, ksn = L.kg / 2;   // k-step index within the layer, tile-major
+        const int rel = (f - kX6KFrags * (L.f0 / 2)) / kX6KFrags, ksn = L.kg / 2;   // k-step index within the layer, tile-major
         const int t = rel / ksn, ks = rel - t * ksn;
         const int n = 32 * t + (lane & 31), h = lane >> 5;
         const int ks0 = L.kg0 >> 1;

@@ -25,12 +25,13 @@ def pose_to_euler_trans(poses):
 
 
 class Network(HeadNetwork):
-    def __init__(self, H, W, focal, near, far, chunk, intrinsic, N_samlpes, N_importance, args: RenderConfig = None,
+    def __init__(self, H, W, focal, near, far, chunk, N_samlpes, N_importance, args: RenderConfig = None,
                  dim_aud_body=64, dim_expr_head=79):
+        """The reference's positional arguments (train_torso.py:185: no `intrinsic`, unlike the head-only Network)."""
         nn.Module.__init__(self)
         self.args = args = args or RenderConfig(dim_expr=dim_expr_head)
         self.H, self.W, self.focal, self.near, self.far = H, W, focal, near, far
-        self.chunk, self.intrinsic = chunk, intrinsic
+        self.chunk, self.intrinsic = chunk, None
         self.N_samples, self.N_importance = N_samlpes, N_importance
         self.output_ch, self.skips = 4, [4]
         self.dim_aud_body = dim_aud_body

@@ -18,10 +18,14 @@ Weights are NOT stored: both this script and the tests rebuild them from
 bias 0.01 as audio_exp_nerf.py:442-448), optionally with the sigma head scaled
 (``sigma_gain``) so the volume is not empty.
 
-The torso variant's extra output (``rgb_map_fg``, TorsoNeRF/run_nerf.py:757) is
-pinned at formula level only: that module's import chain is stale upstream
-(SURVEY.md section 2), so the fixture applies the one-line formula to weights and
-colours produced by the HeadNeRF reference functions.
+The torso variant (``rgb_map_fg``, TorsoNeRF/run_nerf.py:715-766, and the head + torso
+composite, TorsoNeRF/train_torso.py:198-271) comes from the reference's own code as well:
+``NeRFs.TorsoNeRF.run_nerf`` imports with the same stand-ins once ``F`` (which the module
+uses without importing it) is put into its namespace, and ``NeRFs.TorsoNeRF.train_torso``
+once ``get_embedder``'s default device is 'cpu' instead of 'cuda' (it only places the
+frequency table) -- ``python make_golden.py headtorso``.  ``python make_golden.py frame512``
+renders the first 4096 rays of the 512x512 bench frame (BASELINE configs[1]) with the
+reference's ``Network.render_rays``.
 """
 import argparse
 import os
@@ -65,6 +69,19 @@ def install_shims():
     sys.modules["torch.utils.tensorboard"] = tb
     sys.modules["tensorboard"] = types.ModuleType("tensorboard")
     torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def torso_raw2outputs():
+    """NeRFs/TorsoNeRF/run_nerf.py::raw2outputs (:715-766), the reference's own function object.  The module
+    imports with the stand-ins of install_shims(); it uses `F.relu` without importing `F`, which is supplied."""
+    import importlib
+    for p in (REF, os.path.join(REF, "NeRFs", "TorsoNeRF")):   # the module's siblings are imported by bare name upstream
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    rn = importlib.import_module("NeRFs.TorsoNeRF.run_nerf")
+    torch.autograd.set_detect_anomaly(False)   # run_nerf_helpers switches it on at import (:7)
+    rn.F = torch.nn.functional
+    return rn.raw2outputs
 
 
 def load_state(module, params):
@@ -148,8 +165,9 @@ def main():
         bc = f32(rs.uniform(0, 1, size=(n, 3)))
         with torch.no_grad():
             rgb_map, disp, acc, w, depth = baseline.raw2outputs(raw, z, d, bc)
-            rgb = torch.sigmoid(raw[..., :3])
-            rgb_fg = torch.sum(w[:, :-1, None] * rgb[:, :-1, :], -2)  # TorsoNeRF/run_nerf.py:757 (formula level)
+            # the torso variant, by the reference's own function (TorsoNeRF/run_nerf.py:715-766): same five outputs + rgb_map_fg
+            t_rgb_map, t_disp, t_acc, t_w, t_depth, rgb_fg = torso_raw2outputs()(raw, z, d, bc)
+            assert all(torch.equal(a, b) for a, b in ((rgb_map, t_rgb_map), (disp, t_disp), (acc, t_acc), (w, t_w), (depth, t_depth)))
         fx.update({f"s{S}_raw": raw.numpy(), f"s{S}_z": z.numpy(), f"s{S}_d": d.numpy(), f"s{S}_bc": bc.numpy(),
                    f"s{S}_rgb_map": rgb_map.numpy(), f"s{S}_disp": disp.numpy(), f"s{S}_acc": acc.numpy(),
                    f"s{S}_weights": w.numpy(), f"s{S}_depth": depth.numpy(), f"s{S}_rgb_fg": rgb_fg.numpy()})
@@ -549,9 +567,190 @@ def golden_flags():
     print("wrote flags.npz:", sorted(fx)[:6], "...", len(fx), "arrays")
 
 
+def _spy_searchsorted(captured):
+    real = torch.searchsorted
+
+    def spy(cdf, u, **kw):
+        r = real(cdf, u, **kw)
+        captured["cdf"], captured["u"], captured["inds"] = cdf.clone(), u.clone(), r.clone()
+        return r
+
+    return real, spy
+
+
+def golden_frame512():
+    """`python make_golden.py frame512`: BASELINE configs[1] at full size, from the reference itself -- the first 4096
+    rays (rows 0..7) of the 512x512 bench frame (oracle.synthetic_frame(512, 512, seed 0), networks seeds 2 / 3 with the
+    density head x300, as bench.py and __graft_entry__.smoke build them) through the reference's Network.render_rays
+    (audio_exp_nerf.py:297-371), perturb = 0.  Stored: every output for all 4096 rays, the importance indices of all
+    4096 rays (captured at torch.searchsorted), and the merged fine depths of every 8th ray (512 rays) for the
+    given-positions check of tests/parity_proof.py."""
+    install_shims()
+    sys.argv = [sys.argv[0], "--perturb", "0", "--dim_aud", "64", "--dim_expr", "76",
+                "--N_samples", "64", "--N_importance", "128", "--near", str(NEAR), "--far", str(FAR),
+                "--vis_path", "/tmp/idealnerf_golden_vis", "--chunk", "8192"]
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    import oracle
+    import NeRFs.HeadNeRF.helper as helper
+    from NeRFs.HeadNeRF.train import audio_exp_nerf as aen
+    dims = oracle.facenerf_dims()
+    H = W = 512
+    N = 4096
+    syn = oracle.synthetic_frame(H, W, seed=0, dims=dims)
+    net = aen.Network(H, W, syn["focal"], NEAR, FAR, 8192, None, 64, 128)
+    load_state(net.face_nerf_coarse, scale_sigma(oracle.xavier_facenerf_params(2, dims), 300.0, 0.3))
+    load_state(net.face_nerf_fine, scale_sigma(oracle.xavier_facenerf_params(3, dims), 300.0, 0.3))
+    net.eval()
+    ro, rd = helper.get_rays(H, W, syn["focal"], syn["c2w"])
+    viewdirs = rd / torch.norm(rd, dim=-1, keepdim=True)
+    rays = torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), NEAR * torch.ones(H * W, 1), FAR * torch.ones(H * W, 1),
+                      viewdirs.reshape(-1, 3)], -1).float()[:N]
+    bc = syn["bc"].reshape(-1, 3)[:N]
+    captured, taps = {}, {}
+    real_ss, spy = _spy_searchsorted(captured)
+    real_r2o = aen.raw2outputs
+
+    def tap_r2o(raw, z_vals, *a, **k):
+        if raw.shape[1] == 192:
+            taps["z_fine"] = z_vals.detach().clone()
+        return real_r2o(raw, z_vals, *a, **k)
+
+    torch.searchsorted, aen.raw2outputs = spy, tap_r2o
+    try:
+        with torch.no_grad():
+            ret = net.render_rays(rays, bc, syn["aud"], syn["c2w"], syn["latent"], syn["expr"])
+    finally:
+        torch.searchsorted, aen.raw2outputs = real_ss, real_r2o
+    inds = captured["inds"].numpy()
+    assert inds.shape == (N, 128) and inds.min() >= 1 and inds.max() <= 63
+    vis = float((ret["rgb_map"] - bc).abs().mean())
+    fx = dict(n_rays=N, rays_first=rays[:4].numpy(), rays_last=rays[-4:].numpy(), inds=inds.astype(np.uint8),
+              z_fine_every8=taps["z_fine"][::8].numpy(), **{k: v.numpy() for k, v in ret.items()})
+    np.savez_compressed(os.path.join(HERE, "frame512_tile.npz"), **fx)
+    print(f"wrote frame512_tile.npz: {N} rays, visibility {vis:.3f}, "
+          f"{os.path.getsize(os.path.join(HERE, 'frame512_tile.npz')) / 1024:.0f} KiB")
+
+
+def head_torso_inputs(n=512):
+    """The seeded inputs of the head + torso scene (shared with tests/test_hip_parity.py::_torso_setup: same seeds, same
+    draws, in the same order)."""
+    import oracle
+    rs = np.random.RandomState(5)
+    syn = oracle.synthetic_frame(32, 32, seed=4)
+    pose = torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
+    pose0 = torch.eye(4)
+    pose0[:3, 3] = torch.tensor([0.02, -0.01, 0.9])
+    ro, rd = oracle.camera_rays(32, 32, syn["focal"], pose[:3, :4])
+    ro0, rd0 = oracle.camera_rays(32, 32, syn["focal"], pose0[:3, :4])
+    sel = torch.from_numpy(rs.choice(1024, size=n, replace=False))
+    pick = lambda a: a.reshape(-1, 3)[sel]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    return syn, dict(batch_rays=torch.stack([pick(ro), pick(rd)], 0), batch_rays_torso=torch.stack([pick(ro0), pick(rd0)], 0),
+                     bg=pick(syn["bc"]), auds=T(rs.standard_normal((4, 16, 29)).astype(np.float32)), pose=pose,
+                     expr=T(rs.standard_normal(79).astype(np.float32)), latent=torch.ones(32),
+                     target=T(rs.uniform(0, 1, (n, 3)).astype(np.float32)))
+
+
+def golden_head_torso():
+    """`python make_golden.py headtorso`: SURVEY 8 row a11 / BASELINE configs[4] from the reference's own
+    NeRFs/TorsoNeRF/train_torso.py::Network (:198-271) -- forward([x, global_step, dataset_size]) in training mode (the
+    ray-batch branch) under torch.no_grad(): head pair (C = 63 + 64 + 79 + 32) and torso pair (C = 63 + 106) rendered by
+    its render_rays / run_nerf.raw2outputs / run_nerf_helpers.sample_pdf, composited as rgb * last_weight_torso +
+    rgb_fg_torso (:269-270).  512 rays of the sharp test scene (density head x100 on the head pair, x4 on the torso
+    pair).  Weights are rebuilt from seeds by the tests; the audio net's (torch-initialised) are stored."""
+    install_shims()
+    sys.argv = [sys.argv[0], "--perturb", "0", "--dim_aud", "64", "--dim_aud_body", "64", "--N_samples", "64",
+                "--N_importance", "128", "--near", str(NEAR), "--far", str(FAR), "--chunk", "512",
+                "--vis_path", "/tmp/idealnerf_golden_vis"]
+    for p in (REPO, REF, os.path.join(REF, "NeRFs", "TorsoNeRF")):
+        sys.path.insert(0, p)
+    torch.manual_seed(4321)
+    torch.set_num_threads(8)
+    import functools
+    import importlib
+    import oracle
+    helpers = importlib.import_module("NeRFs.TorsoNeRF.run_nerf_helpers")
+    torch.autograd.set_detect_anomaly(False)
+    real_get_embedder = helpers.get_embedder
+    helpers.get_embedder = functools.wraps(real_get_embedder)(lambda multires, i=0, device="cpu": real_get_embedder(multires, i, device))
+    raw2outputs_ref = torso_raw2outputs()      # imports NeRFs.TorsoNeRF.run_nerf and supplies its missing `F`
+    tt = importlib.import_module("NeRFs.TorsoNeRF.train_torso")
+    assert tt.raw2outputs is raw2outputs_ref and tt.args.N_importance == 128 and tt.args.perturb == 0.0
+
+    syn, d = head_torso_inputs(512)
+    n = d["bg"].shape[0]
+    net = tt.Network(32, 32, syn["focal"], NEAR, FAR, 512, 64, 128)
+    dh = oracle.facenerf_dims(dim_aud=64, dim_expr=79, dim_latent=32)
+    dt = oracle.facenerf_dims(dim_aud=106, dim_expr=0, dim_latent=0)
+    load_state(net.face_nerf_coarse, scale_sigma(oracle.xavier_facenerf_params(21, dh), 100.0, 0.2))
+    load_state(net.face_nerf_fine, scale_sigma(oracle.xavier_facenerf_params(22, dh), 100.0, 0.2))
+    load_state(net.torso_coarse_nerf, scale_sigma(oracle.xavier_facenerf_params(23, dt), 4.0, -0.2))
+    load_state(net.torso_fine_nerf, scale_sigma(oracle.xavier_facenerf_params(24, dt), 4.0, -0.2))
+    net.train()
+
+    captured, order = {}, []
+    real_ss, spy = _spy_searchsorted(captured)
+    real_sp, real_rr = tt.sample_pdf, net.render_rays
+    taps = {}
+
+    def tap_sp(bins, weights, N, det=False, pytest=False):
+        torch.searchsorted = spy
+        try:
+            r = real_sp(bins, weights, N, det=det, pytest=pytest)
+        finally:
+            torch.searchsorted = real_ss
+        order.append((captured["inds"].clone(), r.detach().clone()))
+        return r
+
+    def tap_rr(rays, *a, **k):     # keep every render's own outputs (forward only returns the composites)
+        r = real_rr(rays, *a, **k)
+        taps.setdefault("renders", []).append({key: v.detach().clone() for key, v in r.items()})
+        taps.setdefault("rays", []).append(rays.detach().clone())
+        return r
+
+    tt.sample_pdf, net.render_rays = tap_sp, tap_rr
+    x = (d["batch_rays"][None], d["batch_rays_torso"][None], d["target"], d["bg"], d["auds"][None], torch.zeros(1, 32, 32, 3),
+         d["pose"], d["expr"][None], d["latent"], torch.tensor([1]))
+    try:
+        with torch.no_grad():
+            rgb_com, rgb_com0 = net([x, 0, 4])
+    finally:
+        tt.sample_pdf = real_sp
+        del net.render_rays
+    assert len(order) == 2 and len(taps["renders"]) == 2 and rgb_com.shape == (n, 3)
+    head, torso = taps["renders"]
+    # train_torso.py:269-270, once more from the parts the reference itself produced
+    assert torch.equal(rgb_com, head["rgb_map"] * torso["last_weight"][..., None] + torso["rgb_map_fg"])
+    assert torch.equal(rgb_com0, head["rgb0"] * torso["last_weight0"][..., None] + torso["rgb_map_fg0"])
+    with torch.no_grad():
+        aud_feature = net.aud_net(d["auds"][1:2])
+    fx = dict(rgb_com=rgb_com.numpy(), rgb_com0=rgb_com0.numpy(), aud_feature=aud_feature.numpy(),
+              rays_head=taps["rays"][0].numpy(), rays_torso=taps["rays"][1].numpy(),
+              inds_head=order[0][0].numpy().astype(np.uint8), inds_torso=order[1][0].numpy().astype(np.uint8),
+              z_samples_head=order[0][1].numpy(), z_samples_torso=order[1][1].numpy())
+    for tag, r in (("head", head), ("torso", torso)):
+        for k in ("rgb_map", "rgb_map_fg", "rgb0", "rgb_map_fg0", "last_weight", "last_weight0", "z_std", "disp_map", "acc_map"):
+            fx[f"{tag}_{k}"] = r[k].numpy()
+    for k, v in d.items():
+        fx["in_" + k] = v.numpy()
+    for k, v in net.aud_net.state_dict().items():
+        fx["audnet." + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "head_torso.npz"), **fx)
+    e = (rgb_com - d["bg"]).abs().mean()
+    print(f"wrote head_torso.npz: {n} rays, composite visibility {float(e):.3f}, "
+          f"{os.path.getsize(os.path.join(HERE, 'head_torso.npz')) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "flags":
         golden_flags()
+    elif len(sys.argv) > 1 and sys.argv[1] == "frame512":
+        golden_frame512()
+    elif len(sys.argv) > 1 and sys.argv[1] == "headtorso":
+        golden_head_torso()
     elif len(sys.argv) > 1 and sys.argv[1] == "agg":
         golden_agg()
     elif len(sys.argv) > 1 and sys.argv[1] == "torso":

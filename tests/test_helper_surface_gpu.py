@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import oracle
+from parity_proof import flipped_rows, oracle_fine_pass, prove_render
 
 pytestmark = pytest.mark.gpu
 
@@ -390,25 +391,28 @@ def test_obama_configs_render_by_name(idn, dev, cfg_name):
     net.face_nerf_fine.load_state_dict(pf)
     g = lambda t: None if t is None else t.to(dev)
     rows = (8, 14)     # rank 1's band of a 3-way split
+    expr = g(syn["expr"]) if cfg.dim_expr else None
     with torch.no_grad():
         rgb, disp, acc, last_w, extras = net.render_dynamic_face(
-            H, W, syn["focal"], expr=g(syn["expr"]) if cfg.dim_expr else None, poses=syn["c2w"], latent_code=g(syn["latent"]),
+            H, W, syn["focal"], expr=expr, poses=syn["c2w"], latent_code=g(syn["latent"]),
             render_poses=syn["c2w"][:3, :4], chunk=cfg.chunk, near=cfg.near, far=cfg.far, bc_rgb=g(syn["bc"]),
             aud_para=g(syn["aud"]), rows=rows)
         ref = oracle.render_frame(H, W, syn["focal"], syn["c2w"], cfg.near, cfg.far, syn["bc"], pc, pf, syn["aud"],
-                                  syn["expr"] if cfg.dim_expr else None, syn["latent"], dims=dims, rows=rows)
-        ref64 = oracle.render_frame(H, W, syn["focal"], *oracle.to_f64((syn["c2w"], cfg.near, cfg.far, syn["bc"], pc, pf, syn["aud"],
-                                    syn["expr"] if cfg.dim_expr else None, syn["latent"])), dims=dims, rows=rows)
-    assert rgb.shape == (6, W, 3)
-
-    def ok(got, key, tol, err):
-        """within `tol` of the live fp32 oracle, or -- where the fp32 formula itself is that far from fp64 on this
-        scene -- within three times the oracle's own distance of the fp64 result (test_hip_parity.rgb_ok)"""
-        e32, e64, floor = err(got, ref[key]), err(got, ref64[key]), err(ref[key], ref64[key])
-        return e32 < tol or e64 < max(tol, 3.0 * floor)
-
-    # both sit behind the importance sampling; last_weight is bounded by 1 and may be ~1e-17: absolute error
-    assert ok(rgb, "rgb_map", RGB_TOL, rel_err) and ok(last_w, "last_weight", RGB_TOL, abs_err)
+                                  syn["expr"] if cfg.dim_expr else None, syn["latent"], dims=dims, rows=rows, taps=True)
+        # the band once more with the debug taps, by the call render_dynamic_face makes (same rays, same kernels)
+        rays = idn.ops.frame_rays(syn["c2w"][:3, :4], H, W, syn["focal"], cfg.near, cfg.far, rows[0], rows[1] - rows[0], device=dev)
+        bc = g(syn["bc"])[rows[0]:rows[1]].reshape(-1, 3).contiguous()
+        tapped = net.render_rays(rays, bc, g(syn["aud"]), syn["c2w"], g(syn["latent"]), expr, taps=True)
+        ff = net.face_nerf_fine.folded_bias(g(syn["aud"]), expr, g(syn["latent"]))
+    assert rgb.shape == (6, W, 3) and torch.equal(tapped["rgb_map"], rgb.reshape(-1, 3))
+    flat = {k: v.reshape((-1,) + tuple(v.shape[2:])) for k, v in ref.items()}
+    # fixed 1e-4 behind the sampling, exact sampling stage, coarse weights within 1e-5: every ray (tests/parity_proof.py)
+    prove_render(idn, cfg_name.split("/")[-2] + " band", tapped, flat, net.face_nerf_fine.packed_weights(), ff, rays, bc,
+                 lambda z: oracle_fine_pass(pf, dims, rays, bc, syn["aud"], syn["expr"] if cfg.dim_expr else None, syn["latent"], z), 2e-4)
+    fl, _ = flipped_rows(tapped["tap_inds"], flat["tap_inds"])
+    keep = torch.from_numpy(~fl)
+    # last_weight is bounded by 1 and may be ~1e-17: absolute error, on the rays whose sample positions are the oracle's
+    assert abs_err(last_w.reshape(-1)[keep.to(dev)], flat["last_weight"][keep]) < RGB_TOL
     assert rel_err(extras["rgb0"], ref["rgb0"]) < RGB_TOL
 
 

@@ -50,25 +50,12 @@ def abs_err(a, b):
     return np.abs(a - b).max()
 
 
-def rgb_budget(ref32, ref64, tol=None):
-    """Three times the oracle's own fp32-vs-fp64 distance on this scene (oracle.fp32_noise_floor), at least the 1e-4
-    budget -- measured 3e-7 .. 4e-4 on the scenes here."""
-    return max(RGB_TOL if tol is None else tol, 3.0 * rel_err(ref32, ref64))
-
-
-def rgb_ok(out, ref32, ref64, what=""):
-    """Acceptance for a comparison with an oracle evaluated AT RUN TIME (the goldens are fixed numbers; a live
-    oracle run depends on the host's BLAS, and on sharp scenes the fp32 formula itself sits ~1e-4 from exact
-    arithmetic): within the 1e-4 budget of the fp32 oracle -- or, where the oracle's own distance from the same
-    formulas in fp64 is of that size, within three times that distance of the fp64 result (the same order as
-    the reference's own fp32 evaluation: which of two fp32 codes flips a given importance index is luck)."""
-    e32 = rel_err(out, ref32)
-    if e32 < RGB_TOL:
-        return True
-    e64, budget = rel_err(out, ref64), rgb_budget(ref32, ref64)
-    print(f"\n  {what}: {e32:.2e} from the fp32 oracle, {e64:.2e} from fp64 (oracle's own distance "
-          f"{rel_err(ref32, ref64):.2e}, bound {budget:.2e})")
-    return e64 < budget
+# Comparisons with an oracle evaluated at run time use the FIXED 1e-4 -- and where a scene is sharp enough that the
+# importance sampling turns a last-ulp difference of a coarse weight into more than that, the test proves exactly this
+# and nothing more, for every ray (tests/parity_proof.py): coarse weights within 1e-5, the sampling stage bit-exact on
+# the HIP weights, and the fine pass within 1e-4 of the oracle's on the oracle's AND on the HIP sample positions.
+from parity_proof import (check_stage, flipped_rows, hip_fine_pass, oracle_fine_pass, prove, prove_render,  # noqa: E402
+                          small_sample_bound)
 
 
 # Quantities bounded by 1 (weights, transmittance tails, cdf) are compared absolutely.
@@ -86,6 +73,7 @@ CDF_TOL = 3e-4
 Z_STD_TOL = 1.5e-3   # a statistic of the sampled depths
 FLIP_TOL = 2e-4
 FLIP_TOL_X3 = 1.5e-3   # the bf16x3 network output carries 1e-5 instead of 1e-6
+FLIP_TOL_SHARP = 1e-3  # sharp scenes (sigma gain 100..300 on every sample, trained weights): measured 1e-4 .. 4.3e-4
 
 
 def scale_sigma(p, gain=300.0, bias=0.3):
@@ -531,12 +519,16 @@ def test_full_size_band_properties(idn, dev):
     part = run(rays[1000:1777].contiguous(), bc[1000:1777].contiguous())
     assert torch.equal(part["rgb_map"], full["rgb_map"][1000:1777])
     assert torch.equal(part["z_std"], full["z_std"][1000:1777])
-    # CPU oracle on a sample of the same rays
-    idx = torch.arange(0, rays.shape[0], 997)
+    # CPU oracle on every 80th ray of the band (512 rays; the reference-generated tile of this frame is
+    # test_frame512_tile_golden): fixed 1e-4, flips attributed (parity_proof)
+    idx = torch.arange(0, rays.shape[0], 80)
     with torch.no_grad():
-        ref = oracle.render_rays(rays[idx].cpu(), bc[idx].cpu(), pc, pf, *cond, dims=dims)
-        ref64 = oracle.render_rays(*oracle.to_f64((rays[idx].cpu(), bc[idx].cpu(), pc, pf, *cond)), dims=dims)
-    assert rgb_ok(full["rgb_map"][idx], ref["rgb_map"], ref64["rgb_map"], "full-size band")
+        ref = oracle.render_rays(rays[idx].cpu(), bc[idx].cpu(), pc, pf, *cond, dims=dims, taps=True)
+    sub = {k: v[idx.to(dev)] for k, v in full.items()}
+    r_sub, bc_sub = rays[idx.to(dev)].contiguous(), bc[idx.to(dev)].contiguous()
+    prove_render(idn, "full-size band", sub, ref, pk_f, ff, r_sub, bc_sub,
+                 lambda z: oracle_fine_pass(pf, dims, r_sub, bc_sub, *cond, z), FLIP_TOL)
+    assert rel_err(sub["rgb0"], ref["rgb0"]) < RGB_TOL
 
 
 # --------------------------------------------------------------------------- a12: training step
@@ -716,7 +708,7 @@ def _torso_setup(idn, dev, n=48):
     rs = np.random.RandomState(5)
     syn = oracle.synthetic_frame(32, 32, seed=4)
     cfg = RenderConfig(perturb=0.0, chunk=512, near=NEAR, far=FAR, dim_expr=79)
-    net = Network(32, 32, syn["focal"], NEAR, FAR, 512, None, 64, 128, args=cfg).to(dev)
+    net = Network(32, 32, syn["focal"], NEAR, FAR, 512, 64, 128, args=cfg).to(dev)
     dh = oracle.facenerf_dims(dim_aud=64, dim_expr=79, dim_latent=32)
     dt = oracle.facenerf_dims(dim_aud=106, dim_expr=0, dim_latent=0)
     P = dict(hc=scale_sigma(oracle.xavier_facenerf_params(21, dh), 100.0, 0.2),
@@ -740,21 +732,69 @@ def _torso_setup(idn, dev, n=48):
     return net, syn, P, (dh, dt), data
 
 
-def _torso_oracle(net, P, dims, data, grad=False, f64=False):
+def _torso_oracle(net, P, dims, data, grad=False, parts=False):
     dh, dt = dims
     cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
     aud_net = type(net.aud_net)(64, 16); aud_net.load_state_dict(cpu(net.aud_net))
-    if f64:   # the same formulas in double: how far the fp32 oracle itself is from exact arithmetic here
-        aud_net, P, data = aud_net.double(), oracle.to_f64(P), oracle.to_f64(data)
     with torch.set_grad_enabled(grad):
         aud_feature = aud_net(data["auds"][1:2])
         aud_torso = oracle.torso_signal(aud_feature, data["pose"])
         rec = lambda r: oracle.ray_records(r[0], r[1], NEAR, FAR)
         head = oracle.render_rays(rec(data["batch_rays"]), data["bg"], P["hc"], P["hf"], aud_feature, data["expr"],
-                                  data["latent"], dims=dh, with_fg=True)
+                                  data["latent"], dims=dh, with_fg=True, taps=parts)
         torso = oracle.render_rays(rec(data["batch_rays_torso"]), data["bg"], P["tc"], P["tf"], aud_torso, None, None,
-                                   dims=dt, with_fg=True)
+                                   dims=dt, with_fg=True, taps=parts)
+        if parts:
+            return oracle.head_torso_composite(head, torso), head, torso
         return oracle.head_torso_composite(head, torso), aud_net
+
+
+def _torso_hip_parts(net, d, dev):
+    """The two renders behind train_torso.Network.forward (ray-batch branch), with the debug taps: what forward
+    composites, by the same calls (`_render` is what `render_pair` -> `_batchify` reaches)."""
+    g = lambda t: t.to(device=dev, dtype=torch.float32)
+    with torch.no_grad():
+        aud_feature = net.aud_net(g(d["auds"])[1:2])
+        aud_torso = net.torso_signal(aud_feature, g(d["pose"]))
+        def rec(r):   # the records as render_pair builds them, on the device (same ops => same bits as forward)
+            ro, rd = g(r[0]).reshape(-1, 3), g(r[1]).reshape(-1, 3)
+            one = torch.ones_like(rd[..., :1])
+            return torch.cat([ro, rd, NEAR * one, FAR * one, rd / torch.norm(rd, dim=-1, keepdim=True)], -1).contiguous()
+        rays_h, rays_t, bg = rec(d["batch_rays"]), rec(d["batch_rays_torso"]), g(d["bg"]).contiguous()
+        expr, lat = g(d["expr"]), g(d["latent"])
+        head = net._render(rays_h, bg, aud_feature, lat, expr, net.face_nerf_coarse, net.face_nerf_fine, True, taps=True)
+        torso = net._render(rays_t, bg, aud_torso, None, None, net.torso_coarse_nerf, net.torso_fine_nerf, True, taps=True)
+        folds = (net.face_nerf_fine.folded_bias(aud_feature, expr, lat), net.torso_fine_nerf.folded_bias(aud_torso, None, None))
+    return head, torso, rays_h, rays_t, bg, folds
+
+
+def prove_head_torso(idn, what, net, P, dims, d, dev, rgb_com, flip_bound):
+    """parity_proof's (1)-(3) for the composite rgb_head * last_weight_torso + rgb_fg_torso (train_torso.py:269-270): the
+    stage checks on both renders; the composite of the two HIP fine passes against the composite of the two oracle fine
+    passes on the same positions (the oracle's, then the HIP path's), fixed 1e-4, every ray."""
+    (ref, ref0), ref_h, ref_t = _torso_oracle(net, P, dims, d, parts=True)
+    head, torso, rays_h, rays_t, bg, (fold_h, fold_t) = _torso_hip_parts(net, d, dev)
+    hip_com = head["rgb_map"] * torso["last_weight"][..., None] + torso["rgb_map_fg"]
+    assert torch.equal(hip_com.reshape(rgb_com.shape), torch.as_tensor(rgb_com, device=dev, dtype=torch.float32)), "forward composites something else"
+    check_stage(what + " (head)", head, ref_h, 128)
+    check_stage(what + " (torso)", torso, ref_t, 128)
+    fh, ft = net.face_nerf_fine, net.torso_fine_nerf
+    compose = lambda h, t: h["rgb_map"] * t["last_weight"][..., None] + t["rgb_fg"]
+    # HIP fine passes on the oracle's positions (vs the oracle's composite) ...
+    on_ref = compose(hip_fine_pass(idn, fh.packed_weights(), fold_h, rays_h, bg, ref_h["tap_z_fine"], fh.prec_code),
+                     hip_fine_pass(idn, ft.packed_weights(), fold_t, rays_t, bg, ref_t["tap_z_fine"], ft.prec_code, with_fg=True))
+    # ... and the oracle's fine passes on the HIP positions (vs the HIP composite)
+    with torch.no_grad():
+        cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        aud_net = type(net.aud_net)(64, 16); aud_net.load_state_dict(cpu(net.aud_net))
+        aud_feature = aud_net(d["auds"][1:2])
+        aud_torso = oracle.torso_signal(aud_feature, d["pose"])
+    ora_on_hip = compose(oracle_fine_pass(P["hf"], dims[0], rays_h, bg, aud_feature, d["expr"], d["latent"], head["tap_z_fine"]),
+                         oracle_fine_pass(P["tf"], dims[1], rays_t, bg, aud_torso, None, None, torso["tap_z_fine"], with_fg=True))
+    (fl_h, rate_h), (fl_t, rate_t) = flipped_rows(head["tap_inds"], ref_h["tap_inds"]), flipped_rows(torso["tap_inds"], ref_t["tap_inds"])
+    res = prove(what, (on_ref, ref), (hip_com, ora_on_hip), hip_com, ref, fl_h | fl_t, max(rate_h, rate_t, key=float),
+                small_sample_bound(flip_bound, head["tap_inds"].numel()))
+    return res, ref, ref0
 
 
 def test_head_torso_composite_matches_oracle(idn, dev):
@@ -764,10 +804,92 @@ def test_head_torso_composite_matches_oracle(idn, dev):
          d["expr"][None], d["latent"], torch.tensor([1]))
     with torch.no_grad():
         rgb_com, rgb_com0 = net([x, 0, 4])
-    (ref, ref0), _ = _torso_oracle(net, P, dims, d)
-    (ref64, _), _ = _torso_oracle(net, P, dims, d, f64=True)
     assert rgb_com.shape == (48, 3)
-    assert rgb_ok(rgb_com, ref, ref64, "head+torso composite") and rel_err(rgb_com0, ref0) < RGB_TOL
+    _, ref, ref0 = prove_head_torso(idn, "head+torso composite", net, P, dims, d, dev, rgb_com, FLIP_TOL_SHARP)
+    assert rel_err(rgb_com0, ref0) < RGB_TOL
+
+
+def test_head_torso_golden(idn, dev, golden):
+    """a11 / BASELINE configs[4] against the REFERENCE's own TorsoNeRF code (tests/golden/head_torso.npz: train_torso.py
+    Network.forward with run_nerf.raw2outputs' rgb_map_fg and run_nerf_helpers.sample_pdf, 512 rays of the sharp scene):
+    the product's forward with the reference's positional constructor arguments and the reference's audio-net weights."""
+    from idealnerf_amd.train_torso import Network
+    from idealnerf_amd.helper import RenderConfig
+    g = golden("head_torso")
+    net = Network(32, 32, oracle.synthetic_frame(32, 32, seed=4)["focal"], NEAR, FAR, 512, 64, 128,
+                  args=RenderConfig(perturb=0.0, chunk=512, near=NEAR, far=FAR, dim_expr=79)).to(dev)
+    dh = oracle.facenerf_dims(dim_aud=64, dim_expr=79, dim_latent=32)
+    dt = oracle.facenerf_dims(dim_aud=106, dim_expr=0, dim_latent=0)
+    P = dict(hc=scale_sigma(oracle.xavier_facenerf_params(21, dh), 100.0, 0.2), hf=scale_sigma(oracle.xavier_facenerf_params(22, dh), 100.0, 0.2),
+             tc=scale_sigma(oracle.xavier_facenerf_params(23, dt), 4.0, -0.2), tf=scale_sigma(oracle.xavier_facenerf_params(24, dt), 4.0, -0.2))
+    net.face_nerf_coarse.load_state_dict(P["hc"]); net.face_nerf_fine.load_state_dict(P["hf"])
+    net.torso_coarse_nerf.load_state_dict(P["tc"]); net.torso_fine_nerf.load_state_dict(P["tf"])
+    net.aud_net.load_state_dict({k[len("audnet."):]: T(v) for k, v in g.items() if k.startswith("audnet.")})
+    net.train()   # the reference ran its ray-batch branch (render_poses = None); autograd is off
+    d = {k[3:]: T(v) for k, v in g.items() if k.startswith("in_")}
+    x = (d["batch_rays"][None], d["batch_rays_torso"][None], d["target"], d["bg"], d["auds"][None], None, d["pose"],
+         d["expr"][None], d["latent"], torch.tensor([1]))
+    with torch.no_grad():
+        rgb_com, rgb_com0 = net([x, 0, 4])
+    assert rel_err(rgb_com0, g["rgb_com0"]) < RGB_TOL              # no sampling before the coarse composite: 1e-4 outright
+    # the two renders behind forward, with taps, against the reference's own parts
+    head, torso, rays_h, rays_t, bg, (fold_h, fold_t) = _torso_hip_parts(net, d, dev)
+    assert rel_err(rays_h, g["rays_head"]) < 1e-6 and rel_err(rays_t, g["rays_torso"]) < 1e-6
+    assert torch.equal(head["rgb_map"] * torso["last_weight"][..., None] + torso["rgb_map_fg"], rgb_com)
+    for tag, r in (("head", head), ("torso", torso)):
+        for k in ("rgb0", "rgb_map_fg0", "last_weight0"):
+            assert rel_err(r[k], g[f"{tag}_{k}"]) < RGB_TOL, (tag, k)
+        check_stage(f"head+torso golden ({tag})", r, None, 128)     # the sampling stage is exact on the HIP coarse weights
+    # the reference's merged fine depths: its own samples merged with the (bit-exact) coarse depths
+    zf = lambda r, tag: torch.sort(torch.cat([r["tap_z_coarse"].cpu(), T(g[f"z_samples_{tag}"])], -1), -1)[0]
+    fh, ft = net.face_nerf_fine, net.torso_fine_nerf
+    compose = lambda h, t: h["rgb_map"] * t["last_weight"][..., None] + t["rgb_fg"]
+    on_ref = compose(hip_fine_pass(idn, fh.packed_weights(), fold_h, rays_h, bg, zf(head, "head"), fh.prec_code),
+                     hip_fine_pass(idn, ft.packed_weights(), fold_t, rays_t, bg, zf(torso, "torso"), ft.prec_code, with_fg=True))
+    aud_feature = T(g["aud_feature"])
+    with torch.no_grad():
+        aud_torso = oracle.torso_signal(aud_feature, d["pose"])
+    ora_on_hip = compose(oracle_fine_pass(P["hf"], dh, rays_h, bg, aud_feature, d["expr"], d["latent"], head["tap_z_fine"]),
+                         oracle_fine_pass(P["tf"], dt, rays_t, bg, aud_torso, None, None, torso["tap_z_fine"], with_fg=True))
+    (fl_h, rate_h), (fl_t, rate_t) = flipped_rows(head["tap_inds"], g["inds_head"]), flipped_rows(torso["tap_inds"], g["inds_torso"])
+    res = prove("head+torso vs the reference's composite", (on_ref, g["rgb_com"]), (rgb_com, ora_on_hip), rgb_com, g["rgb_com"],
+                fl_h | fl_t, max(rate_h, rate_t, key=float), FLIP_TOL_SHARP)
+    assert res["beyond"] < 0.03 * 512     # a statistic of this scene (measured: 6 rays), not a criterion: the criteria are in prove()
+
+
+def test_frame512_tile_golden(idn, dev, golden):
+    """BASELINE configs[1] at FULL size against the reference itself (tests/golden/frame512_tile.npz: the reference's
+    Network.render_rays on the first 4096 rays of the 512 x 512 bench frame): every output of every ray at the fixed
+    1e-4 / 1e-5 budgets, importance indices against the reference's, and parity_proof's decomposition -- the fine pass on
+    the reference's own sample positions (every 8th ray) and the oracle's fine pass on the HIP positions."""
+    g = golden("frame512_tile")
+    n = int(g["n_rays"])
+    dims, pc, pf, (pk_c, fold_c), (pk_f, fold_f) = _nets(idn, dev)
+    syn = oracle.synthetic_frame(512, 512, seed=0, dims=dims)
+    cond = (syn["aud"], syn["expr"], syn["latent"])
+    rays = idn.ops.frame_rays(syn["c2w"], 512, 512, syn["focal"], NEAR, FAR, row0=0, nrows=n // 512, device=dev)
+    assert rel_err(rays[:4], g["rays_first"]) < 1e-6 and rel_err(rays[-4:], g["rays_last"]) < 1e-6
+    bc = syn["bc"].reshape(-1, 3)[:n].contiguous().to(dev)
+    fc, ff = fold_c(*cond), fold_f(*cond)
+    out = idn.ops.render_rays_fwd(rays, bc, pk_c, fc, pk_f, ff, torch.linspace(0.0, 1.0, 64).to(dev), torch.linspace(0.0, 1.0, 128).to(dev),
+                                  128, taps=True)
+    for k in ("rgb0", "disp0", "acc0"):                       # nothing is sampled before the coarse composite
+        assert rel_err(out[k], g[k]) < RGB_TOL, k
+    check_stage("frame512 tile", out, None, 128)              # the sampling stage is exact on the HIP coarse weights
+    fl, rate = flipped_rows(out["tap_inds"], g["inds"])
+    sub = torch.arange(0, n, 8)
+    sd = sub.to(dev)
+    on_ref = hip_fine_pass(idn, pk_f, ff, rays[sd].contiguous(), bc[sd].contiguous(), T(g["z_fine_every8"]))
+    # the oracle's fine pass on the HIP positions: every 8th ray and every ray that is beyond 1e-4 end to end
+    e2e = np.abs(out["rgb_map"].cpu().numpy().astype(np.float64) - g["rgb_map"]).max(1) / np.abs(g["rgb_map"]).max()
+    pick = torch.from_numpy(np.union1d(sub.numpy(), np.nonzero(e2e > RGB_TOL)[0]))
+    pd = pick.to(dev)
+    ora = oracle_fine_pass(pf, dims, rays[pd], bc[pd], *cond, out["tap_z_fine"][pd])
+    for k in ("rgb_map", "disp_map", "acc_map"):
+        prove(f"frame512 tile {k}", (on_ref[k], g[k][sub.numpy()]), (out[k][pd], ora[k]), out[k], g[k], fl, rate, FLIP_TOL)
+    keep = torch.from_numpy(~fl)
+    assert abs_err(out["last_weight"][keep.to(dev)], g["last_weight"][keep.numpy()]) < W_TOL
+    assert rel_err(out["z_std"][keep.to(dev)], g["z_std"][keep.numpy()]) < Z_STD_TOL
 
 
 def test_torso_signal_golden(idn, dev, golden):
@@ -776,7 +898,7 @@ def test_torso_signal_golden(idn, dev, golden):
     from idealnerf_amd.helper import RenderConfig
     from idealnerf_amd.train_torso import Network, pose_to_euler_trans
     g = golden("torso_signal")
-    net = Network(8, 8, 100.0, NEAR, FAR, 64, None, 64, 128, args=RenderConfig(dim_expr=79)).to(dev)
+    net = Network(8, 8, 100.0, NEAR, FAR, 64, 64, 128, args=RenderConfig(dim_expr=79)).to(dev)
     poses, aud = T(g["poses"]).to(dev), T(g["aud"]).to(dev)
     et = pose_to_euler_trans(poses)
     assert abs_err(et, g["euler_trans"]) < 2e-6          # atan2 / asin: CPU SLEEF vs GPU ocml, last ulps
@@ -1292,13 +1414,16 @@ def test_render_unusual_sample_counts_vs_oracle(idn, dev, n_rays, S, Ni):
     bc = syn["bc"].reshape(-1, 3)[sel].contiguous()
     cond = (syn["aud"], syn["expr"], syn["latent"])
     with torch.no_grad():
-        ref = oracle.render_rays(r.cpu(), bc, pc, pf, *cond, n_samples=S, n_importance=Ni, dims=dims)
-        ref64 = oracle.render_rays(*oracle.to_f64((r.cpu(), bc, pc, pf, *cond)), n_samples=S, n_importance=Ni, dims=dims)
+        ref = oracle.render_rays(r.cpu(), bc, pc, pf, *cond, n_samples=S, n_importance=Ni, dims=dims, taps=True)
     t, u = torch.linspace(0.0, 1.0, S).to(dev), torch.linspace(0.0, 1.0, Ni).to(dev)
-    out = idn.ops.render_rays_fwd(r, bc.to(dev), pk_c, fold_c(*cond), pk_f, fold_f(*cond), t, u, Ni)
-    for k in ("rgb_map", "rgb0", "disp_map", "acc_map"):
-        assert rgb_ok(out[k], ref[k], ref64[k], k), k
-    assert abs_err(out["last_weight"], ref["last_weight"]) < W_TOL
+    ff = fold_f(*cond)
+    out = idn.ops.render_rays_fwd(r, bc.to(dev), pk_c, fold_c(*cond), pk_f, ff, t, u, Ni, taps=True)
+    for k in ("rgb0", "disp0", "acc0"):      # nothing is sampled before the coarse composite
+        assert rel_err(out[k], ref[k]) < RGB_TOL, k
+    prove_render(idn, f"{n_rays} rays {S}+{Ni}", out, ref, pk_f, ff, r, bc.to(dev), lambda z: oracle_fine_pass(pf, dims, r, bc, *cond, z),
+                 FLIP_TOL, keys=("rgb_map", "disp_map", "acc_map"))
+    fl, _ = flipped_rows(out["tap_inds"], ref["tap_inds"])
+    assert abs_err(out["last_weight"][torch.from_numpy(~fl).to(dev)], ref["last_weight"][torch.from_numpy(~fl)]) < W_TOL
 
 
 def test_train_forward_defines_every_row_of_the_activation_slab(idn, dev):
@@ -1364,14 +1489,14 @@ def test_head_torso_composite_bf16_modes_psnr(idn, dev):
     assert rel_err(outs["bf16x3"][1], outs["f32"][1]) < RGB_TOL   # the coarse composite has no importance sampling before it
     # the same three composites against the CPU oracle (pinned to the reference; torso conditioning pinned by
     # tests/golden/torso_signal.npz), each at its mode's budget
-    (ref, ref0), _ = _torso_oracle(net, P, dims, d)
-    (ref64, _), _ = _torso_oracle(net, P, dims, d, f64=True)
-    budget = rgb_budget(ref, ref64)
+    for m in nets:
+        m.precision = "f32"
+    _, ref, ref0 = prove_head_torso(idn, "head+torso fp32 (256 rays)", net, P, dims, d, dev, outs["f32"][0], FLIP_TOL_SHARP)
     ref, ref0 = ref.numpy().astype(np.float64), ref0.numpy().astype(np.float64)
     o3, o1 = psnr(outs["bf16x3"][0], ref), psnr(outs["bf16"][0], ref)
-    print(f"head+torso composite vs CPU oracle: fp32 max rel {rel_err(outs['f32'][0], ref):.1e} (budget {budget:.1e}: the oracle's "
-          f"own fp32-vs-fp64 distance x 2), bf16x3 PSNR {o3:.1f} dB, plain bf16 PSNR {o1:.1f} dB")
-    assert rgb_ok(outs["f32"][0], ref, ref64.numpy(), "head+torso fp32") and rel_err(outs["f32"][1], ref0) < RGB_TOL   # sharp scene: see the mixed test
+    print(f"head+torso composite vs CPU oracle: fp32 max rel {rel_err(outs['f32'][0], ref):.1e}, bf16x3 PSNR {o3:.1f} dB, "
+          f"plain bf16 PSNR {o1:.1f} dB")
+    assert rel_err(outs["f32"][1], ref0) < RGB_TOL
     assert o3 > 60.0 and o1 > 40.0
     assert rel_err(outs["bf16x3"][1], ref0) < RGB_TOL
 
@@ -1390,19 +1515,15 @@ def test_mixed6_and_bf16x6_on_the_sharp_scene(idn, dev):
             idn.set_render_precision(net, mode)
             outs[mode] = [o.cpu().numpy().astype(np.float64) for o in net([x, 0, 4])]
     assert net.face_nerf_coarse.precision == "bf16x6" and net.face_nerf_fine.precision == "bf16x3"
-    (ref, ref0), _ = _torso_oracle(net, P, dims, d)
-    (ref64, _), _ = _torso_oracle(net, P, dims, d, f64=True)
-    budget = rgb_budget(ref, ref64)
-    ref_np = ref.numpy().astype(np.float64)
+    # (the scene is built so that one flipped importance index moves a pixel by ~1e-4: every ray beyond 1e-4 is shown to
+    #  carry a flip, and on the oracle's own positions every mode is inside 1e-4 -- fp32 kernels 0.4-0.8 % of 512 rays
+    #  flipped, the bf16x6 coarse network about twice that, as on the reference's golden frame: 3e-5 vs 1.5e-5 of the indices)
     for mode in ("f32", "bf16x6", "mixed6"):
-        per_ray = np.abs(outs[mode][0] - ref_np).max(1) / np.abs(ref_np).max()
-        e32 = rel_err(outs[mode][0], outs["f32"][0])
-        print(f"\n  {mode:7s}: vs CPU oracle max {per_ray.max():.2e} ({(per_ray > RGB_TOL).mean():.3%} of rays beyond 1e-4; budget {budget:.2e}), "
-              f"vs the fp32 kernels {e32:.2e}, coarse composite vs oracle {rel_err(outs[mode][1], ref0):.2e}")
-        # (the scene is built so that one flipped importance index moves a pixel by ~1e-4: the share of rays beyond 1e-4
-        #  counts flips against the CPU oracle -- fp32 kernels 0.4-0.8 % of 512 rays, the bf16x6 coarse network about twice
-        #  that, as on the reference's golden frame: 3e-5 vs 1.5e-5 of the indices)
-        assert per_ray.max() < budget and (per_ray > RGB_TOL).mean() < (0.01 if mode == "f32" else 0.03), mode
+        idn.set_render_precision(net, mode)
+        res, ref, ref0 = prove_head_torso(idn, f"head+torso {mode}", net, P, dims, d, dev, outs[mode][0],
+                                          FLIP_TOL_SHARP if mode == "f32" else 2 * FLIP_TOL_SHARP)
+        print(f"  {mode:7s}: vs the fp32 kernels {rel_err(outs[mode][0], outs['f32'][0]):.2e}, coarse composite vs oracle {rel_err(outs[mode][1], ref0):.2e}")
+        assert res["beyond"] < (0.01 if mode == "f32" else 0.03) * 512, mode
         assert rel_err(outs[mode][1], ref0) < RGB_TOL, mode      # no sampling before the coarse composite
     idn.set_render_precision(net, "f32")
 
@@ -1426,24 +1547,19 @@ def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golde
     print(f"\nmixed vs fp32 on the head+torso scene (512 rays): max rel err {e:.2e}")
     assert e < RGB_TOL
     np.testing.assert_array_equal(outs["mixed"][1], outs["f32"][1])   # the coarse composite is the same arithmetic
-    (ref, ref0), _ = _torso_oracle(net, P, dims, d)                    # and both against the CPU oracle
-    (ref64, _), _ = _torso_oracle(net, P, dims, d, f64=True)
-    budget = rgb_budget(ref, ref64)
-    eo = rel_err(outs["mixed"][0], ref)
-    print(f"mixed vs CPU oracle on the head+torso scene: max rel err {eo:.2e} (fp32: {rel_err(outs['f32'][0], ref):.2e}; the "
-          f"oracle's own fp32-vs-fp64 distance here: {oracle.fp32_noise_floor(ref, ref64):.2e})")
     # This scene is built to be sharp (sigma gain 100 on the head): a fine sample relocated by one flipped
     # importance index changes its pixel by ~1e-4, whichever fp32 implementation flipped it -- so the two
     # exact-fp32 evaluations (CPU BLAS vs fp32 MFMA) differ by 2e-4 on the worst of 512 rays, and `mixed`
-    # inherits exactly that (it agrees with the fp32 kernel to 4e-6, above).  Bounds: the coarse composite (no
-    # sampling before it) inside the 1e-4 budget; the fine one within three times the oracle's own distance from fp64
-    # (or 1e-4), with under 1 % of the rays beyond 1e-4.
-    ref_np = ref.numpy().astype(np.float64)
+    # inherits exactly that (it agrees with the fp32 kernel to 4e-6, above).  Proved, not assumed (parity_proof):
+    # on the oracle's own sample positions both modes are inside 1e-4 on every ray, and each end-to-end ray beyond
+    # 1e-4 has a flipped index in the head or the torso render; the coarse composite (no sampling before it)
+    # is inside 1e-4 outright.
     for mode in ("f32", "mixed"):
-        per_ray = np.abs(outs[mode][0] - ref_np).max(1) / np.abs(ref_np).max()
-        print(f"  {mode}: rays beyond 1e-4 of the frame maximum: {(per_ray > RGB_TOL).mean():.2%}")
-        assert rgb_ok(outs[mode][0], ref, ref64, f"head+torso {mode}") and (per_ray > RGB_TOL).mean() < 0.01
+        idn.set_render_precision(net, mode)
+        res, ref, ref0 = prove_head_torso(idn, f"head+torso {mode}", net, P, dims, d, dev, outs[mode][0], FLIP_TOL_SHARP)
+        assert res["beyond"] < 0.01 * 512, mode
         assert rel_err(outs[mode][1], ref0) < RGB_TOL
+    idn.set_render_precision(net, "f32")
 
     g = golden("frame32")
     dims32 = oracle.facenerf_dims()
@@ -1463,14 +1579,17 @@ def test_mixed_precision_keeps_the_rgb_budget_on_the_sharp_scene(idn, dev, golde
     assert flips < FLIP_TOL   # the fp32 kernel's own flip rate, not bf16x3's
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
+@pytest.mark.parametrize("seed", [11, 14, 16, 21])
 def test_random_scenes_fp32_and_mixed_vs_oracle(idn, dev, seed):
     """Fresh weights, pose, conditioning and a random ray subset per seed: the fp32 and the mixed mode
     against the CPU oracle (which is pinned to the reference), every output finite."""
     dims = oracle.facenerf_dims()
     rs = np.random.RandomState(seed)
-    pc = scale_sigma(oracle.xavier_facenerf_params(100 + seed, dims), float(rs.uniform(30, 300)), float(rs.uniform(-0.2, 0.4)))
-    pf = scale_sigma(oracle.xavier_facenerf_params(200 + seed, dims), float(rs.uniform(30, 300)), float(rs.uniform(-0.2, 0.4)))
+    # (seeds: round 2's 12 and 13 drew EMPTY volumes -- a Xavier density head is positive or negative over the whole volume --
+    #  so the frame equalled the background bit for bit and the comparison was vacuous; 14, 16, 21 hide a quarter of the
+    #  background in both passes, 11 is the sharp one: dense coarse pass, nearly empty fine pass)
+    pc = scale_sigma(oracle.xavier_facenerf_params(100 + seed, dims), float(rs.uniform(30, 300)), float(rs.uniform(0.1, 0.4)))
+    pf = scale_sigma(oracle.xavier_facenerf_params(200 + seed, dims), float(rs.uniform(30, 300)), float(rs.uniform(0.1, 0.4)))
     syn = oracle.synthetic_frame(32, 32, seed=seed, dims=dims)
     rays = idn.ops.frame_rays(syn["c2w"], 32, 32, syn["focal"], NEAR, FAR, device=dev)
     sel = torch.from_numpy(rs.choice(1024, 160, replace=False))
@@ -1478,9 +1597,8 @@ def test_random_scenes_fp32_and_mixed_vs_oracle(idn, dev, seed):
     bc = syn["bc"].reshape(-1, 3)[sel].contiguous()
     cond = (syn["aud"], syn["expr"], syn["latent"])
     with torch.no_grad():
-        ref = oracle.render_rays(r.cpu(), bc, pc, pf, *cond, n_samples=64, n_importance=128, dims=dims)
-        ref64 = oracle.render_rays(*oracle.to_f64((r.cpu(), bc, pc, pf, *cond)), n_samples=64, n_importance=128, dims=dims)
-    print(f"\nrandom scene {seed}: the oracle's own fp32-vs-fp64 distance on rgb_map = {oracle.fp32_noise_floor(ref['rgb_map'], ref64['rgb_map']):.2e}")
+        ref = oracle.render_rays(r.cpu(), bc, pc, pf, *cond, n_samples=64, n_importance=128, dims=dims, taps=True)
+    assert max(float((ref["rgb_map"] - bc).abs().mean()), float((ref["rgb0"] - bc).abs().mean())) > 0.02, "the volume must hide part of the background"
     t, u = torch.linspace(0.0, 1.0, 64).to(dev), torch.linspace(0.0, 1.0, 128).to(dev)
     for mode, (prec_c, prec_f) in (("f32", (0, 0)), ("mixed", (0, 1))):
         packs = []
@@ -1489,10 +1607,11 @@ def test_random_scenes_fp32_and_mixed_vs_oracle(idn, dev, seed):
             ps = idn.ops.params_struct(sd, 64, 76, 32)
             packs.append((idn.ops.pack_weights(ps, dev, prec), idn.ops.fold_conditioning(ps, *(c.to(dev) for c in cond), dev), sd))
         out = idn.ops.render_rays_fwd(r, bc.to(dev), packs[0][0], packs[0][1], packs[1][0], packs[1][1], t, u, 128,
-                                      precision=prec_c, precision_fine=prec_f)
+                                      precision=prec_c, precision_fine=prec_f, taps=True)
         for k in ("rgb_map", "rgb0", "disp_map", "acc_map", "last_weight", "z_std"):
             assert bool(torch.isfinite(out[k]).all()), (mode, k)
-        assert rgb_ok(out["rgb_map"], ref["rgb_map"], ref64["rgb_map"], f"scene {seed} {mode}"), mode
+        prove_render(idn, f"scene {seed} {mode}", out, ref, packs[1][0], packs[1][1], r, bc.to(dev),
+                     lambda z: oracle_fine_pass(pf, dims, r, bc, *cond, z), FLIP_TOL_SHARP, precision_fine=prec_f)
         assert rel_err(out["rgb0"], ref["rgb0"]) < RGB_TOL, mode   # the coarse composite has no sampling before it
 
 

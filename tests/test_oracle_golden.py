@@ -196,3 +196,54 @@ def test_render_switches_golden(golden):
     near = torch.full((4, 1), 0.5772005200386048)
     far = torch.full((4, 1), 1.1772005200386046)
     np.testing.assert_array_equal(oracle.coarse_depths(near, far, 64, lindisp=True).numpy(), g["rr_lindisp_z_coarse"][:4])
+
+
+def test_head_torso_golden(golden):
+    """SURVEY 8 row a11 against the reference's own TorsoNeRF code (train_torso.py::Network.forward, run_nerf.raw2outputs
+    with its rgb_map_fg, run_nerf_helpers.sample_pdf): the oracle's head render, torso render and composite."""
+    g = golden("head_torso")
+    dh = oracle.facenerf_dims(dim_aud=64, dim_expr=79, dim_latent=32)
+    dt = oracle.facenerf_dims(dim_aud=106, dim_expr=0, dim_latent=0)
+    P = dict(hc=scale_sigma(oracle.xavier_facenerf_params(21, dh), 100.0, 0.2), hf=scale_sigma(oracle.xavier_facenerf_params(22, dh), 100.0, 0.2),
+             tc=scale_sigma(oracle.xavier_facenerf_params(23, dt), 4.0, -0.2), tf=scale_sigma(oracle.xavier_facenerf_params(24, dt), 4.0, -0.2))
+    aud_feature = T(g["aud_feature"])
+    with torch.no_grad():
+        aud_torso = oracle.torso_signal(aud_feature, T(g["in_pose"]))
+        rec = lambda r: oracle.ray_records(r[0], r[1], NEAR, FAR)
+        np.testing.assert_array_equal(rec(T(g["in_batch_rays"])).numpy(), g["rays_head"])     # the reference's own ray records
+        np.testing.assert_array_equal(rec(T(g["in_batch_rays_torso"])).numpy(), g["rays_torso"])
+        head = oracle.render_rays(T(g["rays_head"]), T(g["in_bg"]), P["hc"], P["hf"], aud_feature, T(g["in_expr"]), T(g["in_latent"]),
+                                  dims=dh, with_fg=True, taps=True)
+        torso = oracle.render_rays(T(g["rays_torso"]), T(g["in_bg"]), P["tc"], P["tf"], aud_torso, None, None, dims=dt, with_fg=True, taps=True)
+        rgb_com, rgb_com0 = oracle.head_torso_composite(head, torso)
+    for tag, r in (("head", head), ("torso", torso)):
+        flips = float((r["tap_inds"].numpy() != g[f"inds_{tag}"].astype(np.int64)).mean())
+        assert flips < 2e-4, (tag, flips)     # same code on the same host class: 0 here; a BLAS difference may flip a few
+        for k in ("rgb0", "rgb_map_fg0", "last_weight0"):     # nothing is sampled before the coarse pass
+            assert rel_err(r[k].numpy(), g[f"{tag}_{k}"]) < 2e-6, (tag, k)
+        same = (r["tap_inds"].numpy() == g[f"inds_{tag}"].astype(np.int64)).all(1)
+        for k in ("rgb_map", "rgb_map_fg", "last_weight"):
+            assert rel_err(r[k].numpy()[same], g[f"{tag}_{k}"][same]) < 5e-6, (tag, k)
+    assert rel_err(rgb_com0.numpy(), g["rgb_com0"]) < 2e-6
+    assert rel_err(rgb_com.numpy(), g["rgb_com"]) < 1e-4      # north_star's budget, end to end on the sharp scene
+
+
+def test_frame512_tile_golden(golden):
+    """BASELINE configs[1] at full size: the oracle on the first 4096 rays of the 512 x 512 bench frame against the
+    reference's Network.render_rays (a sixth of the rays here to keep the CPU suite short; all of them in -m gpu)."""
+    g = golden("frame512_tile")
+    dims, pc, pf = _nets()
+    syn = oracle.synthetic_frame(512, 512, seed=0, dims=dims)
+    ro, rd = oracle.camera_rays(512, 512, syn["focal"], syn["c2w"])
+    rays = oracle.ray_records(ro, rd, NEAR, FAR)[:int(g["n_rays"])]
+    np.testing.assert_array_equal(rays[:4].numpy(), g["rays_first"])
+    np.testing.assert_array_equal(rays[-4:].numpy(), g["rays_last"])
+    idx = torch.arange(0, rays.shape[0], 6)
+    with torch.no_grad():
+        out = oracle.render_rays(rays[idx], syn["bc"].reshape(-1, 3)[idx], pc, pf, syn["aud"], syn["expr"], syn["latent"], dims=dims, taps=True)
+    flips = float((out["tap_inds"].numpy() != g["inds"][idx.numpy()].astype(np.int64)).mean())
+    assert flips < 2e-4, flips
+    for k in ("rgb_map", "rgb0", "disp_map", "acc_map", "disp0", "acc0"):
+        assert rel_err(out[k].numpy(), g[k][idx.numpy()]) < 1e-5, k
+    on8 = (idx % 8 == 0)
+    assert rel_err(out["tap_z_fine"][on8].numpy(), g["z_fine_every8"][(idx[on8] // 8).numpy()]) < 1e-6
