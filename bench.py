@@ -215,12 +215,17 @@ def init_ranks(need_gpu=True):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("IDN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     dev = None
+    backend = os.environ.get("IDN_DIST_BACKEND", "nccl") if (world > 1 or os.environ.get("IDN_DIST_INIT_WORLD1") == "1") else None
     if need_gpu:
+        # one process per GPU: say so before a communicator is built on a device that does not exist
+        # (device_count() does not initialise the GPU on this image; ranks sharing a device is the gloo rehearsal only)
+        have = torch.cuda.device_count()
+        if "IDN_FORCE_DEVICE" not in os.environ and (local >= have or (backend == "nccl" and world > have)):
+            sys.exit(f"bench.py: rank {rank} of {world} needs GPU {local}, but this node exposes {have} GPU(s): run with --gpus <= {have} "
+                     "(one process per GPU over RCCL), or rehearse with IDN_DIST_BACKEND=gloo IDN_FORCE_DEVICE=0")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    backend = None
-    if world > 1:
-        backend = os.environ.get("IDN_DIST_BACKEND", "nccl")
+    if backend is not None:
         import datetime
         limit = datetime.timedelta(seconds=int(os.environ.get("IDN_DIST_TIMEOUT_S", "300")))   # a rank that never shows up is an error, not a 30-minute wait
         if backend == "nccl":
@@ -229,6 +234,11 @@ def init_ranks(need_gpu=True):
             dist.init_process_group(backend, timeout=limit)
         assert dist.get_world_size() == world
     return world, rank, dev, backend
+
+
+def dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def bench_rendezvous(args):
@@ -254,6 +264,13 @@ def bench_rendezvous(args):
 
 
 def bench_train(args):
+    """BASELINE configs[2] as its own line (`--workload train`); the default line carries the same measurement as `train_step`."""
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    print(json.dumps(train_measurement(dev, args.steps, args.warmup)))
+
+
+def train_measurement(dev, steps, warmup):
     """BASELINE configs[2]: May HeadNeRF train step, N_rand=3072 (2432 uniform + 512 mouth box + 128
     outside the face rect), fwd + bwd + Adam, single GPU.  Secondary measurement; not the headline."""
     import idealnerf_amd
@@ -261,8 +278,8 @@ def bench_train(args):
     from idealnerf_amd.audio_exp_nerf import Network
     from idealnerf_amd.helper import RenderConfig
     import numpy as np
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
+    import types
+    args = types.SimpleNamespace(steps=steps, warmup=warmup)
     torch.manual_seed(0)   # perturb=1 draws the stratified offsets from torch's generator: same run, same loss
     H = W = 450
     syn = synthetic.frame(H, W, seed=0)
@@ -319,7 +336,7 @@ def bench_train(args):
     ach = sum(fl.values()) / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None
     # blended peak of families with different peaks: total FLOP / (sum of each family's ideal time), so frac = ideal / actual
     peak = sum(fl.values()) / sum(fl[k] / peaks[k] for k in fl)
-    print(json.dumps({"metric": "train ray-samples/sec (N_rand=3072, 64+128, fwd+bwd+Adam)", "value": samples / dt,
+    return ({"metric": "train ray-samples/sec (N_rand=3072, 64+128, fwd+bwd+Adam)", "value": samples / dt,
                       "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f32", "data": "synthetic",
@@ -342,7 +359,7 @@ def bench_train(args):
                                            "families' blended peak (fp32 MFMA 157.3; the x6 GEMMs bf16 peak / 6 = 419.4); "
                                            "the rest of a step is compositing fwd/bwd, sampling, partial-slab reductions, "
                                            "audio net, Adam"},
-                      "final_loss": float(info["loss"])}))
+                      "final_loss": float(info["loss"])})
 
 
 def bench_torso(args):
@@ -355,8 +372,23 @@ def bench_torso(args):
     from idealnerf_amd.train_torso import Network
     import torch.distributed as dist
     world, rank, dev, backend = init_ranks()
-    H = W = args.size
-    prec = args.precision if args.precision_given else "bf16"
+    res = torso_measurement(dev, args.size, args.precision if args.precision_given else "bf16", args.steps, args.warmup, world, rank, backend)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist_on():
+        dist.destroy_process_group()
+
+
+def torso_measurement(dev, size, prec, steps, warmup, world=1, rank=0, backend=None):
+    """The measurement behind `--workload torso` and behind the default line's `torso_composite` block (world = 1)."""
+    import idealnerf_amd
+    from idealnerf_amd import synthetic
+    from idealnerf_amd.helper import RenderConfig
+    from idealnerf_amd.train_torso import Network
+    import torch.distributed as dist
+    import types
+    args = types.SimpleNamespace(steps=steps, warmup=warmup)
+    H = W = size
     syn = synthetic.frame(H, W, seed=rank)   # every rank renders a different frame of the clip
     cfg = RenderConfig(perturb=0.0, chunk=32768, near=syn["near"], far=syn["far"], dim_expr=76)
     net = Network(H, W, syn["focal"], syn["near"], syn["far"], 32768, 64, 128, args=cfg, dim_expr_head=76).to(dev).eval()
@@ -404,9 +436,8 @@ def bench_torso(args):
             ref = step()
             idealnerf_amd.set_render_precision(net, prec)
         psnr = float(-10.0 * torch.log10(((frame.double() - ref.double()) ** 2).mean().clamp_min(1e-30)))
-    if rank == 0:
-        samples = world * args.steps * H * W * 2 * 256
-        print(json.dumps({"metric": "ray-samples/sec (head + torso composite, 64+128 pts each, whole job)", "value": samples / dt,
+    samples = world * args.steps * H * W * 2 * 256
+    return ({"metric": "ray-samples/sec (head + torso composite, 64+128 pts each, whole job)", "value": samples / dt,
                           "unit": "ray-samples/s", "n_gpus": world, "ranks": world, "backend": backend,
                           "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -420,12 +451,10 @@ def bench_torso(args):
                                        "frac": k_pts * FLOP_PER_SAMPLE / (k_ms * 1e-3) / 1e12 / mode_peaks()[prec] if k_ms > 0 else None,
                                        "traffic": None, "launches": k_n, "avg_launch_ms": k_ms / k_n if k_n else None,
                                        "flop_per_sample": FLOP_PER_SAMPLE, "kernel_time_share": (k_ms * 1e-3) / dt},
-                          "finite": bool(torch.isfinite(frame).all()), "psnr_vs_fp32_frame_db": psnr}))
-    if world > 1:
-        dist.destroy_process_group()
+                          "finite": bool(torch.isfinite(frame).all()), "psnr_vs_fp32_frame_db": psnr})
 
 
-def network_api_measurement(args, syn, coarse, fine, c_abi_value, c_abi_tile, frames=3):
+def network_api_measurement(args, syn, coarse, fine, c_abi_value, c_abi_tile, frames=3, perturb=0.0):
     """The same frame through the drop-in surface a reference caller uses: ``Network.forward([data, global_step,
     dataset_size])`` in eval mode with the reference's default ``chunk = 8192`` (helper.py:54), audio net and
     conditioning fold included, against the number measured on ``ops.render_rays_fwd`` above."""
@@ -433,7 +462,7 @@ def network_api_measurement(args, syn, coarse, fine, c_abi_value, c_abi_tile, fr
     from idealnerf_amd.helper import RenderConfig
     dev = c_abi_tile.device
     H, W = syn["H"], syn["W"]
-    cfg = RenderConfig(perturb=0.0, chunk=8192, near=syn["near"], far=syn["far"])
+    cfg = RenderConfig(perturb=perturb, chunk=8192, near=syn["near"], far=syn["far"])
     torch.manual_seed(0)
     net = Network(H, W, syn["focal"], syn["near"], syn["far"], 8192, None, 64, 128, args=cfg).to(dev).eval()
     net.face_nerf_coarse.load_state_dict(coarse.state_dict())
@@ -456,6 +485,14 @@ def network_api_measurement(args, syn, coarse, fine, c_abi_value, c_abi_tile, fr
                                           render_poses=pose[:3, :4], chunk=8192, near=syn["near"], far=syn["far"],
                                           bc_rgb=syn["bc"].to(dev), aud_para=syn["aud"].to(dev))[0]
     v = H * W * 256 / dt
+    if perturb > 0.:
+        # the reference's DEFAULT eval mode (helper.py:70: --perturb 1.0): stratified depths and random u, drawn per chunk as
+        # upstream draws them, so batchify_rays keeps its chunk loop: 32 C calls, 64 folds and 64 torch.rand draws per frame
+        return {"value": v, "unit": "ray-samples/s", "ms_per_frame": dt * 1e3, "ratio_to_c_abi": v / c_abi_value, "perturb": perturb,
+                "chunks_per_frame": (H * W + 8191) // 8192, "finite": bool(torch.isfinite(rgb).all()),
+                "psnr_vs_deterministic_frame_db": float(-10.0 * torch.log10(((rgb.reshape(-1, 3).double() - c_abi_tile.reshape(-1, 3).double()) ** 2).mean().clamp_min(1e-30))),
+                "call": "Network.forward([data, global_step, dataset_size]) in eval mode with the reference's default perturb = 1.0 and "
+                        "chunk = 8192: t_rand and u drawn per chunk (torch.rand on the device), one C call per chunk"}
     return {"value": v, "unit": "ray-samples/s", "ms_per_frame": dt * 1e3, "ratio_to_c_abi": v / c_abi_value,
             "identical_to_c_abi_frame": bool(torch.equal(net_rgb.reshape(-1, 3), c_abi_tile.reshape(-1, 3))),
             "call": "Network.forward([data, global_step, dataset_size]) in eval mode, chunk=8192, AudioNet + both folds per "
@@ -529,22 +566,32 @@ def main():
     pk_c, pk_f = coarse.packed_weights(), fine.packed_weights()
     prec, prec_f = coarse.prec_code, fine.prec_code
 
-    def step():
+    collective = dist_on()   # world > 1, or the one-rank RCCL communicator of IDN_DIST_INIT_WORLD1=1 (the collective then runs at world size 1)
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(i=None):
         # per frame: pose -> rays, conditioning -> biases, then the per-ray path, then the tile exchange
+        if i is not None:
+            marks[i][0].record()
         rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0, device=dev)
         fc = coarse.folded_bias(aud, expr, latent)
         ff = fine.folded_bias(aud, expr, latent)
         out = ops.render_rays_fwd(rays, bc, pk_c, fc, pk_f, ff, t_vals, u, Ni, precision=prec, precision_fine=prec_f)
         tile = out["rgb_map"].reshape(r1 - r0, W, 3)
-        return parallel.gather_rows(tile, H), tile
+        if i is not None:
+            marks[i][1].record()
+        frame = parallel.gather_rows(tile, H, force=collective)
+        if i is not None:
+            marks[i][2].record()   # the collective is ordered into this stream: the event fires when the gathered frame is usable
+        return frame, tile
 
     def fence():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:   # communicator set-up and the first all-gather of this size are not part of any step (--warmup 0 is legal)
-        parallel.gather_rows(torch.zeros((r1 - r0, W, 3), device=dev), H)
+    if collective:   # communicator set-up and the first all-gather of this size are not part of any step (--warmup 0 is legal)
+        parallel.gather_rows(torch.zeros((r1 - r0, W, 3), device=dev), H, force=True)
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
@@ -552,8 +599,8 @@ def main():
         lib.idealnerf_profile_begin()
         first, mismatched = None, torch.zeros((), dtype=torch.int64, device=dev)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            frame, tile = step()
+        for i_step in range(args.steps):
+            frame, tile = step(i_step)
             if args.soak:
                 if first is None:
                     first = tile.clone()
@@ -569,6 +616,15 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # what each rank's GPU did with a step, by HIP events on the launch stream: render (rays + folds + the per-ray path) and
+    # the tile all-gather (which includes waiting for the slowest rank's tile); mean over the timed steps, gathered to rank 0
+    mine = torch.tensor([sum(m[0].elapsed_time(m[1]) for m in marks) / args.steps, sum(m[1].elapsed_time(m[2]) for m in marks) / args.steps,
+                         k_ms.value / args.steps], dtype=torch.float64, device=dev)
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    per_rank = [[float(v) for v in t.tolist()] for t in per_rank]
 
     if rank == 0:
         traffic, traffic_source = pmc_traffic(args.precision)
@@ -592,6 +648,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 in/out, fp32 accumulate)", "bf16": "bf16 (fp32 in/out, fp32 accumulate; PSNR-only parity)", "mixed": "f32 coarse network + bf16x3 fine network", "mixed6": "bf16x6 (fp32-grade) coarse network + bf16x3 fine network", "fp16x3": "fp16x3 (fp32 in/out, fp32 accumulate)", "bf16x6": "bf16x6 (operands as three bf16 pieces = 24 significand bits, fp32 accumulate: fp32-grade)"}[args.precision], "data": "synthetic",
             "per_gpu": value / world, "rays_per_s": value / (S + S + Ni),
+            "per_rank": {"render_ms": [r[0] for r in per_rank], "all_gather_ms": [r[1] for r in per_rank], "mlp_kernel_ms": [r[2] for r in per_rank],
+                         "step_ms_min": min(r[0] + r[1] for r in per_rank), "step_ms_max": max(r[0] + r[1] for r in per_rank),
+                         "note": "HIP events on each rank's launch stream, mean per timed step: render = rays + conditioning folds + the per-ray path; "
+                                 "all_gather = the RCCL tile exchange as this rank sees it (includes waiting for the slowest band)"},
             **({"soak_mismatched_frames": int(mismatched.item())} if args.soak else {}),
             "config": {"workload": f"BASELINE configs[1]: May HeadNeRF {H}x{W} full-frame render, N_sample=64 "
                                    "N_importance=128, dim_aud=64 dim_expr=76 latent=32, perturb=0",
@@ -621,7 +681,8 @@ def main():
                                "product, fp32 accumulate: fp32-grade (<= 2^-23 per product), fp32's range; priced against bf16 peak / 6")
             notes["mixed6"] = ("coarse network (drives the importance sampling) in bf16x6 -- fp32-grade on the bf16 pipe --, fine network in "
                                "bf16x3; priced against the blended peak of the two kernels")
-            for other in (["bf16x6", "mixed6", "fp16x3", "mixed", "bf16x3"] if args.precision == "f32" else ["f32"]):
+            # (fp16x3 / bf16x3 are narrower than the reference's arithmetic: `--precision fp16x3|bf16x3` measures them, the default line no longer does)
+            for other in (["bf16x6", "mixed6", "mixed"] if args.precision == "f32" else ["f32"]):
                 set_mode(other)
                 pko_c, pko_f = coarse.packed_weights(), fine.packed_weights()
                 code_c, code_f = coarse.prec_code, fine.prec_code
@@ -650,13 +711,22 @@ def main():
             set_mode(args.precision)
         if world == 1 and not args.no_f32_mode:
             res["network_api"] = network_api_measurement(args, syn, coarse, fine, value, tile)
+            res["network_api_perturb1"] = network_api_measurement(args, syn, coarse, fine, value, tile, frames=2, perturb=1.0)
+            # BASELINE configs[2] and configs[4] beside the headline, each with its own roofline block, after the timed region
+            t_side = time.perf_counter()
+            tr = train_measurement(dev, steps=8, warmup=4)
+            res["train_step"] = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "final_loss")}
+            to = torso_measurement(dev, H, "bf16", steps=3, warmup=1)
+            res["torso_composite"] = {k: to[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "frames_per_s", "config",
+                                                         "roofline", "finite", "psnr_vs_fp32_frame_db")}
+            res["side_blocks_s"] = time.perf_counter() - t_side
         if world == 1 and not args.no_cpu_baseline:
             pc = {k: v.detach().cpu() for k, v in coarse.state_dict().items()}
             pf = {k: v.detach().cpu() for k, v in fine.state_dict().items()}
             res["cpu_baseline"], psnr = cpu_baseline(syn, pc, pf, tile, r0)
             res["psnr_vs_cpu_oracle_db"] = psnr
         print(json.dumps(res))
-    if world > 1:
+    if dist_on():
         dist.destroy_process_group()
 
 

@@ -8,38 +8,113 @@
 // rate.  (bf16x3 keeps two pieces per operand and three products: 1e-5; the third piece is what makes this one
 // fp32-grade.  The training step's 256 x 256 weight-gradient GEMMs use the same arithmetic, train.hip.)
 //
-// Same computation, stream machinery and tile-major layer order as the other MLP kernels.  What differs is where a
-// layer's data lives: the INPUT of a layer is held as pieces (8 tiles x 3 pieces x 2 k-steps x 4 registers = 192
-// registers per wave of 32 points), its OUTPUT as the fp32 accumulator tiles themselves (8 x 16 = 128 registers,
-// like the fp32 kernel); at the end of a layer the accumulators are ReLU'd and split into the piece registers,
-// which the finished layer no longer needs.  (Input and output both as pieces -- the bf16x3 kernel's two ping-pong
-// sets -- would be 384 registers before accumulators and encodings.)
+// K-MAJOR layers (round 3).  A layer walks its 16-channel k-steps in order and, inside a k-step, its n-tiles: step
+// (s, t) = six piece products of k-step s into accumulator tile t.  The B operand of a k-step -- the three pieces of 16
+// input channels of the wave's 32 points -- is therefore live for ONE k-step only, and it is produced where it is
+// needed: while k-step s runs on the matrix pipe, the vector unit ReLUs and splits the eight accumulator registers of
+// the previous layer that k-step s + 1 consumes (one word pair at a time, in the MFMA shadow).  Two sets of eight
+// accumulator tiles alternate as output and input of consecutive layers; the activations never exist as 192 registers
+// of pieces, and no conversion sits between layers.  (Round 2 was tile-major: a layer's whole input as pieces, its
+// output as accumulators, and 13 % of the pass in the conversions at the layer ends.)
 //
-// Weight stream: per (n-tile, 16-channel k-step) a TRIPLE of fragments (p1, p2, p3) in 48-fragment ring slots: a slice is
-// 16 k-steps, as in the bf16x3 stream (16 pairs), so every layer starts where it does there modulo the ring, slices hold
-// whole triples, and the 3.375 MiB stream stays in the per-XCD L2 (idn_internal.h).
+// Weight stream: per step a TRIPLE of fragments (p1, p2, p3) in 48-fragment ring slots: a slice is 16 steps, every
+// layer starts where it does in the other streams modulo the ring, and the 3.375 MiB stream stays in the per-XCD L2.
 #include "mlp_x6.h"
 
 namespace idn {
 namespace x6 {
 
-constexpr int f0(int l) { return kX6KFrags * plain_f0(l); }   // triples: 3 fragments per k-step (plain_f0 counts k-steps)
+constexpr int f0(int l) { return kX6KFrags * plain_f0(l); }   // triples: 3 fragments per step (plain_f0 counts steps)
 
-// One layer, tile-major: for each n-tile t, KS k-steps of six piece products into O[t].  bget(ic<q>, ic<s>) =
-// piece q of k-step s of the layer's input.  The first fragments arrive in `pref` (issued by the layer before, or
-// here when the layer starts on a slice boundary) and leave in it for the next layer, VALID (retired): the
-// conversion between two layers is long, and a register with a read in flight must not be moved or spilled.
-struct NoTileSide {
-    template <int T, int S>
-    __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {}
+// tile-step at which word W (of 4) of the next k-step's pieces is produced: after tile 0 (whose accumulator the first
+// k-step of the NEXT layer reads: it is complete after step (KS - 1, 0)), spread over the k-step
+constexpr int conv_slot(int nt, int w) { return nt == 1 ? 0 : 1 + (w * (nt - 1)) / 4; }
+
+// The training variant records a half tile where it is converted: the sign bits of the eight pre-activations into the
+// layer's mask words, the ReLU applied in place, two 16-byte stores into this lane's row of the layer's activation
+// matrix (register 4 q + j of tile T is channel 32 T + 8 q + 4 h + j), then the split.
+struct Recorder {
+    uint32_t* mk;     // the mask words of the layer being recorded (dword T / 2: tiles T, T + 1, value r at bit 31 - (16 (T & 1) + r))
+    float* row;       // first float of this lane's row of that layer's matrix + 4 h
 };
-template <int F0, int NT, int KS, int OPEN_YOUNGER = 0, int MID_YOUNGER = 0, class BGet, class Side = NoTileSide, class Hook = NoHook>
-__device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGet&& bget, WStream6& ws, FragReader& fr,
-                                          f32x4 (&pref)[3], Side&& side = NoTileSide{}, Hook&& after_open = NoHook{}) {
+
+template <int T, int HS, int W, bool SAVE>
+__device__ __forceinline__ void convert_word(f32x16& acc, KP& out, const Recorder& rec) {
+    constexpr int r0 = 8 * HS + 2 * W;
+    if constexpr (SAVE) {
+        rec.mk[T >> 1] = __builtin_amdgcn_alignbit(rec.mk[T >> 1], __float_as_uint(acc[r0]), 31);
+        rec.mk[T >> 1] = __builtin_amdgcn_alignbit(rec.mk[T >> 1], __float_as_uint(acc[r0 + 1]), 31);
+        acc[r0] = relu1(acc[r0]);
+        acc[r0 + 1] = relu1(acc[r0 + 1]);
+        float w1, w2, w3;
+        split3(acc[r0], acc[r0 + 1], w1, w2, w3);
+        out.p[0][W] = w1;
+        out.p[1][W] = w2;
+        out.p[2][W] = w3;
+    } else {
+        float w1, w2, w3;
+        split3(relu1(acc[r0]), relu1(acc[r0 + 1]), w1, w2, w3);
+        out.p[0][W] = w1;
+        out.p[1][W] = w2;
+        out.p[2][W] = w3;
+    }
+}
+template <int T, int Q>
+__device__ __forceinline__ void store_quad(const f32x16& acc, const Recorder& rec) {
+#ifdef IDN_TIMING_NO_ROW_STORES   // timing-only experiment (wrong results): what do the row stores cost?
+    return;
+#endif
+    *reinterpret_cast<f32x4*>(rec.row + 32 * T + 8 * Q) = f32x4{acc[4 * Q], acc[4 * Q + 1], acc[4 * Q + 2], acc[4 * Q + 3]};
+}
+
+// tile-steps at which the two row stores of a prepared half tile are issued (training): behind the words of their quad, and
+// in an 8-tile layer at tile-steps 6 and 7, i.e. AFTER the twelve LDS-DMA pieces a wave issues in steps 0..5 of a slice
+constexpr int store_slot(int nt, int q) { return nt >= 8 ? nt - 2 + q : conv_slot(nt, 3); }
+
+// The side work of step (.., t) of a k-step of NT tiles that prepares half tile (T, HS) of `acc` as the next k-step's
+// pieces: words at conv_slot(NT, 0..3); training: the two row stores of the half tile at store_slot(NT, 0 / 1).
+template <int NT, int t, int T, int HS, bool SAVE>
+__device__ __forceinline__ void prepare_half(f32x16& acc, KP& out, const Recorder& rec) {
+    static_for<4>([&](auto W_) {
+        constexpr int w = decltype(W_)::value;
+        if constexpr (conv_slot(NT, w) == t) convert_word<T, HS, w, SAVE>(acc, out, rec);
+    });
+    if constexpr (SAVE) {
+        static_assert(store_slot(NT, 0) >= conv_slot(NT, 1) && store_slot(NT, 1) >= conv_slot(NT, 3), "a quad is stored after its words");
+        if constexpr (t == store_slot(NT, 0)) store_quad<T, 2 * HS>(acc, rec);
+        if constexpr (t == store_slot(NT, 1)) store_quad<T, 2 * HS + 1>(acc, rec);
+    }
+}
+// Row stores issued by step (s, t) of a layer whose k-steps [from, to) each prepare a half tile (training; `to` may be KS + 1:
+// the layer's last k-step prepares the next layer's first).  On gfx9 stores count in vmcnt, vmcnt retires in issue order, and
+// a slice barrier waits for the wave's pieces of the next slice -- which are issued in steps 0..5 of a slice.  The stores
+// issued from step 5 of a slice on are therefore YOUNGER than those pieces and may stay in flight across the barrier: the
+// barrier waits vmcnt(their number) instead of vmcnt(0).  The number is counted from this table at compile time -- never
+// more than were issued (tools/audit_asm_loads.py checks the compiled ISA).
+template <int NT, int FROM, int TO, bool SAVE>
+struct Stores {
+    static constexpr int at(int s, int t) {
+        return (SAVE && s + 1 >= FROM && s + 1 < TO) ? (t == store_slot(NT, 0)) + (t == store_slot(NT, 1)) : 0;
+    }
+    // stores of the steps [i0, i1] of the layer (clipped to it)
+    static constexpr int in_steps(int i0, int i1, int np) {
+        int n = 0;
+        for (int i = (i0 < 0 ? 0 : i0); i <= i1 && i < np; ++i) n += at(i / NT, i % NT);
+        return n;
+    }
+};
+constexpr int kFirstYoungStep = 5;   // in-slice step from which a wave's stores are younger than its pieces of the next slice
+
+// One layer, K-major.  On entry O[0..NT) hold the layer's biases, B the pieces of its k-step 0, `pref` the fragments
+// of its first step (unless the layer starts on a slice boundary).  side(ic<s>, ic<t>, Bn) runs inside step (s, t) and
+// fills Bn, the pieces of the NEXT k-step (of this layer, or -- in the layer's last k-step -- of the next layer, along
+// with that layer's biases).  ST: the row stores the side work issues (training), see Stores.
+template <int F0, int NT, int KS, int OPEN_YOUNGER, class ST, class Side, class Hook>
+__device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WStream6& ws, FragReader& fr, f32x4 (&pref)[3], Hook&& after_open) {
     constexpr int NP = NT * KS;
+    constexpr int kSliceSteps = kX6SliceFrags / kX6KFrags;
     constexpr bool LAST = (F0 + kX6KFrags * NP == kX6UsedFrags);
-    static_assert(F0 % kX6KFrags == 0 && KS >= 4, "triples; the next tile's bias rides on the first four k-steps");
-    bias_tile(O[0], bias_half);
+    static_assert(F0 % kX6KFrags == 0, "triples");
     if constexpr (F0 % kX6SliceFrags == 0) {
         ws.template open_slice<OPEN_YOUNGER>();   // (training: the row stores of the layer before stay in flight)
         after_open();
@@ -49,9 +124,10 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
         static_assert(std::is_same_v<std::decay_t<Hook>, NoHook>, "a hook needs a layer that starts on a slice boundary");
     }
     f32x4 a[3] = {pref[0], pref[1], pref[2]};
+    KP Bn = B;
     static_for<NP>([&](auto PI) {
         constexpr int pi = decltype(PI)::value;
-        constexpr int t = pi / KS, s = pi % KS;
+        constexpr int s = pi / NT, t = pi % NT;
         constexpr int f = F0 + kX6KFrags * pi;
         constexpr bool next_crosses = ((f + kX6KFrags) % kX6SliceFrags == 0);
         constexpr bool has_next = !(LAST && pi + 1 == NP);
@@ -63,101 +139,53 @@ __device__ __forceinline__ void run_layer(f32x16* O, const float* bias_half, BGe
             if constexpr (pi > 0) retire3<0>(a);
         }
         step_pieces6<f>(ws);
-        const f32x4 b1 = bget(ic<0>{}, ic<s>{}), b2 = bget(ic<1>{}, ic<s>{}), b3 = bget(ic<2>{}, ic<s>{});
-        O[t] = mfma_bf(a[0], b1, O[t]);   // w1 a1
-        O[t] = mfma_bf(a[0], b2, O[t]);   // w1 a2
-        O[t] = mfma_bf(a[1], b1, O[t]);   // w2 a1
-        if constexpr (t + 1 < NT && s < 4) bias_quad<s>(O[t + 1], bias_half + 32 * (t + 1));   // the next tile starts from its bias
-        O[t] = mfma_bf(a[1], b2, O[t]);   // w2 a2
-        side(ic<t>{}, ic<s>{});           // training, 256 x 256 layers: tile t - 1 is recorded in this tile's second half (RecordInShadow)
-        O[t] = mfma_bf(a[0], b3, O[t]);   // w1 a3
-        O[t] = mfma_bf(a[2], b1, O[t]);   // w3 a1
+        // (an order of the six products that changes fewer MFMA operands between consecutive instructions -- w3a1, w1a1, w2a1,
+        //  w2a2, w1a2, w1a3 and the reverse in odd tile-steps -- measured -0.5 %: profiles/r03_ab_x6_product_order.log)
+        O[t] = mfma_bf(a[0], B.p[0], O[t]);   // w1 a1
+        O[t] = mfma_bf(a[0], B.p[1], O[t]);   // w1 a2
+        O[t] = mfma_bf(a[1], B.p[0], O[t]);   // w2 a1
+        side(ic<s>{}, ic<t>{}, Bn);           // the next k-step's pieces, in this one's MFMA shadow
+        O[t] = mfma_bf(a[1], B.p[1], O[t]);   // w2 a2
+        O[t] = mfma_bf(a[0], B.p[2], O[t]);   // w1 a3
+        O[t] = mfma_bf(a[2], B.p[0], O[t]);   // w3 a1
         if constexpr (next_crosses && pi + 1 < NP) {
-            // MID_YOUNGER (training, layers whose tiles are slices): the row stores issued in the second half of the slice
-            // that ends here -- none in tile 0 -- are younger than the pieces of the slice being opened
-            ws.template open_slice<(t >= 1 ? MID_YOUNGER : 0)>();
+            // the slice that ends with this step: its steps from kFirstYoungStep on (those of them that belong to this layer)
+            constexpr int y = ST::in_steps(pi - (kSliceSteps - 1) + kFirstYoungStep, pi, NP);
+            ws.template open_slice<y>();
             static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value>(fr); });
         }
         a[0] = n[0];
         a[1] = n[1];
         a[2] = n[2];
+        if constexpr (t == NT - 1) B = Bn;
     });
-    // hand over retired fragments (those of the next layer's first k-step, when this layer ends inside a slice)
+    // hand over retired fragments (those of the next layer's first step, when this layer ends inside a slice)
     if constexpr (!LAST && (F0 + kX6KFrags * NP) % kX6SliceFrags != 0) retire3<0>(a);
     pref[0] = a[0];
     pref[1] = a[1];
     pref[2] = a[2];
 }
-
-// Training: a tile is RECORDED once its accumulator is complete -- the sign bits of the 16 pre-activations into the
-// layer's mask word, the ReLU applied in place, the 16 values into this lane's row of the layer's activation matrix
-// (`row` = its first float + 4 h; register 4 q + j of tile t is channel 32 t + 8 q + 4 h + j, so a quad of registers is
-// 16 contiguous bytes of the row).  On gfx9 stores count in vmcnt, vmcnt retires in issue order, and every slice barrier
-// waits for the wave's pieces of the next slice: a store issued BEFORE those pieces delays the barrier until it has
-// reached L2.  RecordSide is the plain form, for layers whose tiles are not slices: all tiles after the layer, and all
-// of them before any is converted, so that the burst drains behind the conversion's ~3 000 cycles of vector work.
-// (Tile t - 1 at steps 0..2 of tile t -- older than the pieces -- made every barrier of the layer wait: 4.96 -> 5.36 ms.)
-struct RecordSide {
-    f32x16* O;
-    uint32_t* mk;
-    float* row;
-    float* lin;   // timing-only experiment: first float of this wave's 32 rows + 4 lane
-    template <int T>
-    __device__ __forceinline__ void signs_relu(ic<T>) const {
-        collect_signs<T>(O[T], mk);
-        relu_regs<0, 16>(O[T]);
-    }
-    template <int T, int Q0>
-    __device__ __forceinline__ void store2(ic<T>, ic<Q0>) const {
-#ifdef IDN_TIMING_NO_ROW_STORES   // timing-only experiment (wrong results): what do the row stores cost?
-        return;
-#endif
-        static_for<2>([&](auto I) {
-            constexpr int q = Q0 + decltype(I)::value;
-            *reinterpret_cast<f32x4*>(row + 32 * T + 8 * q) = f32x4{O[T][4 * q], O[T][4 * q + 1], O[T][4 * q + 2], O[T][4 * q + 3]};
-        });
-    }
-    template <int T>
-    __device__ __forceinline__ void whole(ic<T>) const {
-        signs_relu(ic<T>{});
-        store2(ic<T>{}, ic<0>{});
-        store2(ic<T>{}, ic<2>{});
-    }
-    template <int T, int Q>
-    __device__ __forceinline__ void store1(ic<T>, ic<Q>) const {
-#ifdef IDN_TIMING_NO_ROW_STORES
-        return;
-#endif
-#ifdef IDN_TIMING_LINEAR_ROW_STORES   // timing-only (wrong layout): the same bytes into the same 32 rows, 1 KiB contiguous per instruction
-        *reinterpret_cast<f32x4*>(lin + (T * 4 + Q) * 256) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
-        return;
-#endif
-        *reinterpret_cast<f32x4*>(row + 32 * T + 8 * Q) = f32x4{O[T][4 * Q], O[T][4 * Q + 1], O[T][4 * Q + 2], O[T][4 * Q + 3]};
-    }
-};
-// A 256 x 256 layer's tile is exactly one slice of the stream (16 k-steps x 3 fragments), and a wave issues its pieces of
-// the next slice in the FIRST half of a slice (two at each of k-steps 0..5).  Tile t - 1 is therefore recorded in the SECOND half of tile t (sign bits
-// and ReLU at step 7, one row store at each of steps 8, 10, 12, 14): those four stores are younger than the pieces the barrier at
-// the end of the tile waits for, and vmcnt retires in issue order, so that barrier waits `vmcnt(4)` and the stores get
-// the next one and a half slices to reach memory, spread over the layer instead of one burst of 32 at its end.
-struct RecordInShadow : RecordSide {
-    template <int T, int S>
-    __device__ __forceinline__ void operator()(ic<T>, ic<S>) const {
-        if constexpr (T > 0) {
-            if constexpr (S == 7) signs_relu(ic<T - 1>{});
-            // one store at each of steps 8, 10, 12, 14: the four waves of a CU run in lockstep, and 4 KiB of stores per k-step
-            // is twice what the chip's write path takes from a CU (at 8, 9, 10, 11: forward 4.73 -> 4.63 ms)
-            if constexpr (S >= 8 && S < 16 && (S & 1) == 0) store1(ic<T - 1>{}, ic<(S - 8) / 2>{});
-        }
-    }
-};
-
-// End of a layer: the NT accumulator tiles are split into the piece registers (the next layer's input), ReLU'd on
-// the way unless the training path has already done that in place.
-template <int NT, bool RELU>
-__device__ __forceinline__ void convert_layer(const f32x16* O, PTile6* P) {
-    static_for<NT>([&](auto T) { convert_tile<RELU>(O[decltype(T)::value], P[decltype(T)::value]); });
+// the stores of a layer's last slice that are younger than the pieces of the slice the NEXT layer opens first (that layer
+// must start on a slice boundary): the layer's last kSliceSteps - kFirstYoungStep steps
+template <class ST, int NT, int KS>
+constexpr int tail_younger() {
+    return ST::in_steps(NT * KS - (kX6SliceFrags / kX6KFrags - kFirstYoungStep), NT * KS - 1, NT * KS);
 }
+
+// a hidden layer (kernel body, `hidden`): k-steps S0 .. KS - 1 come from the input accumulators (prepared during k-steps
+// S0 - 1 .. KS - 2), and its last k-step prepares the next layer's first unless that one is an encoding k-step
+template <int NT, int KS, int S0, bool NEXT_PE, bool SAVE>
+using HiddenStoresT = Stores<NT, (S0 > 0 ? S0 : 1), (NEXT_PE ? KS : KS + 1), SAVE>;
+// views_linears.0: k-steps 1..15 from the trunk, 16 and 17 direction pieces, and its last k-step prepares views_linears.1's first
+template <bool SAVE>
+struct Views0StoresT {
+    static constexpr int at(int s, int t) { return Stores<5, 1, 16, SAVE>::at(s, t) + Stores<5, 18, 19, SAVE>::at(s, t); }
+    static constexpr int in_steps(int i0, int i1, int np) {
+        int n = 0;
+        for (int i = (i0 < 0 ? 0 : i0); i <= i1 && i < np; ++i) n += at(i / 5, i % 5);
+        return n;
+    }
+};
 
 template <int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
@@ -243,109 +271,140 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
             pack_feats(pe_f, pe_p, ic<4>{});
             pack_feats(pd_f, pd_p, ic<2>{});
         }
-
         DIAG_END(dg, kDgInput);
-        PTile6 Pt[8];
-        f32x16 O[8];
-        auto tiles = [&](auto Q, auto S_) {
-            constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
-            return Pt[s >> 1].p[q][s & 1];
+
+        f32x16 X[8], Y[8];   // two sets of accumulator tiles: output and input of consecutive layers, alternating
+        using Views0Stores = Views0StoresT<SAVE>;
+        KP B;
+        uint32_t mk[4] = {0u, 0u, 0u, 0u};   // SAVE: the ReLU mask bits of the layer being recorded
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        auto pe_kstep = [&](auto S_, KP& dst) {
+            constexpr int s = decltype(S_)::value;
+            dst.p[0] = pe_p[0][s];
+            dst.p[1] = pe_p[1][s];
+            dst.p[2] = pe_p[2][s];
         };
-        uint32_t mk[4] = {0u, 0u, 0u, 0u};   // SAVE: the current layer's ReLU mask bits
-        // One hidden layer: MFMAs (training: with the finished tiles recorded in their shadow), then the accumulators
-        // become the next layer's input pieces.  `idx` = the layer's matrix in the activation slab (LD floats per row).
-        // (always_inline: left to its heuristics hipcc made the inference variant's eight identical calls a real function,
-        //  with the 320 registers of O and Pt passed through scratch memory: 11x slower)
-        // Training: how many vector-memory operations are younger than a wave's pieces of the slice a layer opens FIRST:
-        // after a layer recorded in the shadow (above) the 4 row stores of tile 6 + the 4 of tile 7 (+ the mask store); after a
-        // layer recorded at its end 32 + 1.  Never more than were issued (the count must not reach back into the pieces): 8
-        // serves both, and the one code instance of layers 1..4 follows both kinds.
-#ifndef IDN_TEST_OPEN_YOUNGER        // (overridden only by the audit tool's own negative test: tests/test_boundary_cpu.py)
-#define IDN_TEST_OPEN_YOUNGER 8
-#define IDN_TEST_MID_YOUNGER 4
-#endif
-        constexpr int kOpenYounger = IDN_TEST_OPEN_YOUNGER, kMidYounger = IDN_TEST_MID_YOUNGER;
-        auto layer = [&](auto F0c, auto NTc, auto KSc, auto LDc, const float* bias_l, auto&& bget, int idx, auto&& hook) __attribute__((always_inline)) {
-            constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KS = decltype(KSc)::value, LD = decltype(LDc)::value;
-            constexpr bool tile_is_slice = NT == 8 && KS == 16 && F0 % kX6SliceFrags == 0;
+        auto pd_kstep = [&](auto S_, KP& dst) {
+            constexpr int s = decltype(S_)::value;
+            dst.p[0] = pd_p[0][s];
+            dst.p[1] = pd_p[1][s];
+            dst.p[2] = pd_p[2][s];
+        };
+        auto act_row = [&](int idx, int ld) { return SAVE ? a.acts + (long)act_off(idx) * a.p_pad + P * ld + 4 * h : nullptr; };
+        auto mask_store = [&](int idx) {   // the finished mask words of layer `idx`; the next layer's start from zero
             if constexpr (SAVE) {
-                float* row = a.acts + (long)act_off(idx) * a.p_pad + P * LD + 4 * h;
-                if constexpr (tile_is_slice) {
-                    const RecordInShadow rec{{O, mk, row, row - (P - (P & ~31L)) * LD - 4 * h + 4 * lane}};
-                    run_layer<F0, NT, KS, kOpenYounger, kMidYounger>(O, bias_l, bget, ws, fr, pref, rec, hook);
-                    DIAG_BEGIN(dg);
-                    rec.whole(ic<NT - 1>{});
-                } else {
-                    const RecordSide rec{O, mk, row, row};
-                    run_layer<F0, NT, KS, (F0 > 0 ? kOpenYounger : 0)>(O, bias_l, bget, ws, fr, pref, NoTileSide{}, hook);
-                    DIAG_BEGIN(dg);
-                    static_for<NT>([&](auto T) { rec.whole(T); });
-                }
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(idx - kActA1, a.p_pad, tile * 4 + wave, lane);
                 *mp = u32x4{mk[0], mk[1], mk[2], mk[3]};
-                convert_layer<NT, false>(O, Pt);
-                DIAG_END(dg, kDgBoundary);
-            } else {
-                run_layer<F0, NT, KS>(O, bias_l, bget, ws, fr, pref, NoTileSide{}, hook);
-                DIAG_BEGIN(dg);
-                convert_layer<NT, true>(O, Pt);
-                DIAG_END(dg, kDgBoundary);
+                mk[0] = mk[1] = mk[2] = mk[3] = 0u;
             }
         };
-        // ---- pts_linears.0 : PE(64) -> 256
-        layer(ic<f0(0)>{}, ic<8>{}, ic<4>{}, ic<256>{}, bias_h + bias_off(0),
-              [&](auto Q, auto S_) { return pe_p[decltype(Q)::value][decltype(S_)::value]; }, kActA1 + 0, NoHook{});
-        // ---- pts_linears.1..4 : one code instance (a 256 x 256 layer is four ring lengths of the stream)
-#pragma unroll 1
-        for (int l = 1; l <= 4; ++l) layer(ic<f0(1)>{}, ic<8>{}, ic<16>{}, ic<256>{}, bias_h + l * 256, tiles, kActA1 + l, NoHook{});
-        // ---- pts_linears.5 : [PE(64) | 256] -> 256
-        layer(ic<f0(5)>{}, ic<8>{}, ic<20>{}, ic<256>{}, bias_h + bias_off(5),
-              [&](auto Q, auto S_) {
-                  constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
-                  if constexpr (s < 4) return pe_p[q][s];
-                  else return Pt[(s - 4) >> 1].p[q][(s - 4) & 1];
-              },
-              kActA1 + 5, [&]() { load_point<MODE>(a, tile + gridDim.x, wave, m, nxt); });
-        // ---- pts_linears.6, .7
-        layer(ic<f0(6)>{}, ic<8>{}, ic<16>{}, ic<256>{}, bias_h + bias_off(6), tiles, kActA1 + 6, [&]() { touch_point(nxt); });
-        layer(ic<f0(7)>{}, ic<8>{}, ic<16>{}, ic<256>{}, bias_h + bias_off(7), tiles, kActA1 + 7, NoHook{});
-        // ---- views_linears.0 (+ alpha_linear as channel 128): [256 | dirPE(32)] -> 160.
-        //      Tiles 0..3 are hidden units (recorded, converted); tile 4 is neither: its row 0 is sigma.
-        float sigma;
-        {
-            auto bget8 = [&](auto Q, auto S_) {
-                constexpr int q = decltype(Q)::value, s = decltype(S_)::value;
-                if constexpr (s < 16) return Pt[s >> 1].p[q][s & 1];
-                else return pd_p[q][s - 16];
+        // the next layer's biases, loaded into the set its input no longer occupies, one tile per step of this layer's last k-step
+        auto bias_next = [&](auto T_, auto NTnext, f32x16* On, const float* bias_l) {
+            constexpr int t = decltype(T_)::value;
+            if constexpr (t < decltype(NTnext)::value) bias_tile(On[t], bias_l + 32 * t);
+        };
+
+        // ---------------------------------------------------------------------------------------------------------
+        // A hidden layer whose input is the previous layer's accumulators `In` (from k-step S0 on; k-steps [0, S0) are
+        // point-encoding pieces), output tiles `Out`.  During k-step s the vector unit prepares k-step s + 1:
+        //   s + 1 <  S0 : the encoding pieces (a copy);
+        //   s + 1 >= S0 : half tile ((s + 1 - S0) / 2, (s + 1 - S0) % 2) of In -- recorded (training) under activation
+        //                 index `in_idx` with rows of `in_ld` floats;
+        //   s + 1 == KS : the NEXT layer's first k-step -- half tile (0, 0) of Out (recorded under out_idx), unless that
+        //                 layer starts with encoding pieces (next_pe) -- and that layer's biases into `In`.
+        // ---------------------------------------------------------------------------------------------------------
+        auto hidden = [&](auto F0c, auto NTc, auto KSc, auto S0c, auto OYc, f32x16* In, f32x16* Out, int in_idx, int in_ld, int out_idx, int out_ld,
+                          auto NTnext, const float* bias_nxt, auto next_pe, auto&& tail_pieces, auto&& hook) __attribute__((always_inline)) {
+            constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KS = decltype(KSc)::value, S0 = decltype(S0c)::value;
+            constexpr bool NEXT_PE = decltype(next_pe)::value;
+            const Recorder rin{mk, act_row(in_idx, in_ld)}, rout{mk, act_row(out_idx, out_ld)};
+            auto side = [&](auto S_, auto T_, KP& Bn) {
+                constexpr int s = decltype(S_)::value, t = decltype(T_)::value, sn = s + 1;
+                if constexpr (sn < S0) {
+                    if constexpr (t == 0) pe_kstep(ic<sn>{}, Bn);
+                } else if constexpr (sn < KS) {
+                    constexpr int T = (sn - S0) >> 1, HS = (sn - S0) & 1;
+                    prepare_half<NT, t, T, HS, SAVE>(In[T], Bn, rin);
+                    // the mask words of the layer being recorded are complete with its last half tile
+                    if constexpr (SAVE && sn == KS - 1 && t == NT - 1) mask_store(in_idx);
+                } else {
+                    bias_next(T_, NTnext, In, bias_nxt);
+                    if constexpr (NEXT_PE) {
+                        if constexpr (t == 0) tail_pieces(Bn);
+                    } else {
+                        prepare_half<NT, t, 0, 0, SAVE>(Out[0], Bn, rout);
+                    }
+                }
             };
-            if constexpr (SAVE) {
-                const RecordSide rec{O, mk, a.acts + (long)act_off(kActV1) * a.p_pad + P * 128 + 4 * h, nullptr};
-                run_layer<f0(8), 5, 18, kOpenYounger>(O, bias_h + bias_off(8), bget8, ws, fr, pref);
-                static_for<4>([&](auto T) { rec.whole(T); });
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                u32x4* mp = reinterpret_cast<u32x4*>(a.acts + (size_t)kActCols * a.p_pad) + mask_index(kActV1 - kActA1, a.p_pad, tile * 4 + wave, lane);
-                *mp = u32x4{mk[0], mk[1], mk[2], mk[3]};
-                sigma = O[4][0];  // channel 128 = tile 4, register 0, lane half 0
-                convert_layer<4, false>(O, Pt);
-            } else {
-                run_layer<f0(8), 5, 18>(O, bias_h + bias_off(8), bget8, ws, fr, pref);
-                sigma = O[4][0];
-                convert_layer<4, true>(O, Pt);
-            }
+            run_layer<F0, NT, KS, decltype(OYc)::value, HiddenStoresT<NT, KS, S0, NEXT_PE, SAVE>>(Out, B, side, ws, fr, pref, hook);
+        };
+
+        // ---- biases of pts_linears.0, pieces of its first k-step
+        static_for<8>([&](auto T_) { bias_tile(X[decltype(T_)::value], bias_h + bias_off(0) + 32 * decltype(T_)::value); });
+        pe_kstep(ic<0>{}, B);
+        const auto no_tail = [](KP&) {};
+        // row stores still in flight when a layer opens its first slice = the young stores of the layer before it
+        constexpr int kY_L0 = tail_younger<HiddenStoresT<8, 4, 4, false, SAVE>, 8, 4>();        // pts_linears.0: only its last k-step prepares
+        constexpr int kY_H = tail_younger<HiddenStoresT<8, 16, 0, false, SAVE>, 8, 16>();       // a 256 x 256 layer
+        constexpr int kY_L4 = tail_younger<HiddenStoresT<8, 16, 0, true, SAVE>, 8, 16>();       // pts_linears.4: its last k-step hands over encoding pieces
+        constexpr int kY_L5 = tail_younger<HiddenStoresT<8, 20, 4, false, SAVE>, 8, 20>();
+        // ---- pts_linears.0 : PE(64) -> 256 (into X).  Its k-steps are encoding pieces; its last one prepares (X[0], half 0).
+        hidden(ic<f0(0)>{}, ic<8>{}, ic<4>{}, ic<4>{}, ic<0>{}, Y, X, kActA1, 256, kActA1 + 0, 256, ic<8>{}, bias_h + bias_off(1), ic<0>{}, no_tail, NoHook{});
+        // ---- pts_linears.1..4
+        hidden(ic<f0(1)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_L0>{}, X, Y, kActA1 + 0, 256, kActA1 + 1, 256, ic<8>{}, bias_h + bias_off(2), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(2)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_H>{}, Y, X, kActA1 + 1, 256, kActA1 + 2, 256, ic<8>{}, bias_h + bias_off(3), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(3)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_H>{}, X, Y, kActA1 + 2, 256, kActA1 + 3, 256, ic<8>{}, bias_h + bias_off(4), ic<0>{}, no_tail, NoHook{});
+        // pts_linears.4's output (a5) is not the first thing pts_linears.5 reads: its first four k-steps are the encoding
+        hidden(ic<f0(4)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_H>{}, Y, X, kActA1 + 3, 256, kActA1 + 4, 256, ic<8>{}, bias_h + bias_off(5), ic<1>{},
+               [&](KP& Bn) { pe_kstep(ic<0>{}, Bn); }, NoHook{});
+        // ---- pts_linears.5 : [PE(64) | 256] -> 256 (X -> Y)
+        hidden(ic<f0(5)>{}, ic<8>{}, ic<20>{}, ic<4>{}, ic<kY_L4>{}, X, Y, kActA1 + 4, 256, kActA1 + 5, 256, ic<8>{}, bias_h + bias_off(6), ic<0>{}, no_tail,
+               [&]() { load_point<MODE>(a, tile + gridDim.x, wave, m, nxt); });
+        // ---- pts_linears.6, .7
+        hidden(ic<f0(6)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_L5>{}, Y, X, kActA1 + 5, 256, kActA1 + 6, 256, ic<8>{}, bias_h + bias_off(7), ic<0>{}, no_tail, [&]() { touch_point(nxt); });
+        hidden(ic<f0(7)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_H>{}, X, Y, kActA1 + 6, 256, kActA1 + 7, 256, ic<5>{}, bias_h + bias_off(8), ic<0>{}, no_tail, NoHook{});
+        // ---- views_linears.0 (+ alpha_linear as channel 128): [256 | dirPE(32)] -> 160 (Y -> X[0..4]).
+        //      Tiles 0..3 are hidden units; tile 4 is not: its row 0 is sigma.  k-steps 16, 17 are direction pieces.
+        {
+            constexpr int F0 = f0(8), NT = 5, KS = 18;
+            const Recorder rin{mk, act_row(kActA1 + 7, 256)}, rout{mk, act_row(kActV1, 128)};
+            auto side = [&](auto S_, auto T_, KP& Bn) {
+                constexpr int s = decltype(S_)::value, t = decltype(T_)::value, sn = s + 1;
+                if constexpr (sn < 16) {
+                    prepare_half<NT, t, (sn >> 1), (sn & 1), SAVE>(Y[sn >> 1], Bn, rin);
+                    if constexpr (SAVE && sn == 15 && t == NT - 1) mask_store(kActA1 + 7);
+                } else if constexpr (sn < KS) {
+                    if constexpr (t == 0) pd_kstep(ic<sn - 16>{}, Bn);
+                } else {
+                    bias_next(T_, ic<4>{}, Y, bias_h + bias_off(9));
+                    prepare_half<NT, t, 0, 0, SAVE>(X[0], Bn, rout);
+                }
+            };
+            run_layer<F0, NT, KS, kY_H, Views0Stores>(X, B, side, ws, fr, pref, NoHook{});
         }
+        const float sigma = X[4][0];   // channel 128 = tile 4, register 0, lane half 0
         // ---- views_linears.1, .2 : 128 -> 128
-        layer(ic<f0(9)>{}, ic<4>{}, ic<8>{}, ic<128>{}, bias_h + bias_off(9), tiles, kActV1 + 1, NoHook{});
-        layer(ic<f0(10)>{}, ic<4>{}, ic<8>{}, ic<128>{}, bias_h + bias_off(10), tiles, kActV1 + 2, NoHook{});
-        // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile)
-        run_layer<f0(11), 1, 8>(O, bias_h + bias_off(11), tiles, ws, fr, pref);
+        hidden(ic<f0(9)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<0>{}, X, Y, kActV1, 128, kActV1 + 1, 128, ic<4>{}, bias_h + bias_off(10), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(10)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<0>{}, Y, X, kActV1 + 1, 128, kActV1 + 2, 128, ic<1>{}, bias_h + bias_off(11), ic<0>{}, no_tail, NoHook{});
+        // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile, Y[0]); its k-steps record v3
+        {
+            const Recorder rin{mk, act_row(kActV1 + 2, 128)};
+            auto side = [&](auto S_, auto T_, KP& Bn) {
+                constexpr int sn = decltype(S_)::value + 1;
+                if constexpr (sn < 8) {
+                    prepare_half<1, 0, (sn >> 1), (sn & 1), SAVE>(X[sn >> 1], Bn, rin);
+                    if constexpr (SAVE && sn == 7) mask_store(kActV1 + 2);
+                }
+            };
+            run_layer<f0(11), 1, 8, 0, Stores<1, 1, 8, SAVE>>(Y, B, side, ws, fr, pref, NoHook{});
+        }
         finish_pass6<kX6UsedFrags, kX6StreamFrags>(ws);
 
         if (valid && h == 0) {
             f32x4 o;
-            o.x = O[0][0];
-            o.y = O[0][1];
-            o.z = O[0][2];
+            o.x = Y[0][0];
+            o.y = Y[0][1];
+            o.z = Y[0][2];
             o.w = sigma;
             *reinterpret_cast<f32x4*>(a.raw + P * 4) = o;
         }

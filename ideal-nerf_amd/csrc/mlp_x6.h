@@ -11,11 +11,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// (low half, high half) = (bf16(x0), bf16(x1)), round to nearest even
+// (low half, high half) = (bf16(x0), bf16(x1)), round to nearest even: one v_cvt_pk_bf16_f32.  Through the compiler's own
+// conversion, NOT inline asm: the hazard recogniser does not look inside asm, and a piece word written by an asm VALU
+// instruction and read as an MFMA operand three instructions later came back as garbage (the K-major kernel consumes
+// pieces right where they are produced; round 2's tile-major kernel consumed them a layer later and never noticed).
 __device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
-    return r;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t));
 }
 // one packed word of each of the three pieces of two fp32 values (inputs are ordinary VALU results)
 __device__ __forceinline__ void split3(float x0, float x1, float& w1, float& w2, float& w3) {
@@ -29,6 +32,10 @@ __device__ __forceinline__ void split3(float x0, float x1, float& w1, float& w2,
     w3 = __uint_as_float(cvt_pk_bf16(r0, r1));
 }
 
+// The three pieces of one 16-channel k-step of a wave's 32 points: the B operands of that k-step's six products.
+struct KP {
+    f32x4 p[3];
+};
 // The pieces of one 32-channel tile of activations: piece q, k-step s (two 16-channel k-steps per tile).
 struct PTile6 {
     f32x4 p[3][2];

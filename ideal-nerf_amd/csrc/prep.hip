@@ -95,8 +95,8 @@ __global__ void pack_bf16x3_kernel(PackDesc d, uint4* out, int fmt) {
     out[gid] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// six-piece stream: fragment triple (3p .. 3p+2) of a tile = pieces p1, p2, p3 of one 16-channel k-step; same lane /
-// element order as the bf16x3 stream.  p1 = bf16(w), p2 = bf16(w - p1), p3 = bf16(w - p1 - p2).
+// six-piece stream: fragment triple (3p .. 3p+2) = pieces p1, p2, p3 of one step (one n-tile of one 16-channel k-step;
+// steps in K-major order within a layer); same lane / element order inside a fragment as the bf16x3 stream.  p1 = bf16(w), p2 = bf16(w - p1), p3 = bf16(w - p1 - p2).
 __global__ void pack_bf16x6_kernel(PackDesc d, uint4* out) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= kX6StreamFrags * 64) return;
@@ -107,8 +107,9 @@ __global__ void pack_bf16x6_kernel(PackDesc d, uint4* out) {
         int l = 0;
         while (l + 1 < kNumLayers && f >= kX6KFrags * (d.L[l + 1].f0 / 2)) ++l;   // L.f0 counts two fragments per k-step
         const PackLayer& L = d.L[l];
-        const int rel = (f - kX6KFrags * (L.f0 / 2)) / kX6KFrags, ksn = L.kg / 2;   // k-step index within the layer, tile-major
-        const int t = rel / ksn, ks = rel - t * ksn;
+        // step index within the layer, K-MAJOR (mlp_bf16x6.hip): all n-tiles of k-step 0, then of k-step 1, ...
+        const int rel = (f - kX6KFrags * (L.f0 / 2)) / kX6KFrags;
+        const int ks = rel / L.nt, t = rel - ks * L.nt;
         const int n = 32 * t + (lane & 31), h = lane >> 5;
         const int ks0 = L.kg0 >> 1;
         const int src = ks < ks0 ? 0 : 1;

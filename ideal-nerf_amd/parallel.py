@@ -25,11 +25,12 @@ def all_bands(H: int, world: int) -> List[Tuple[int, int]]:
     return [row_band(H, r, world) for r in range(world)]
 
 
-def gather_rows(tile: torch.Tensor, H: int, group=None) -> torch.Tensor:
+def gather_rows(tile: torch.Tensor, H: int, group=None, force: bool = False) -> torch.Tensor:
     """tile: this rank's [rows_r, W, C] band -> the full [H, W, C] frame on every rank.
     Bands may differ by one row, so tiles are padded to the widest band for the
-    fixed-size all_gather and trimmed afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    fixed-size all_gather and trimmed afterwards.  ``force``: issue the collective even on a
+    one-rank communicator (how a one-GPU box exercises the RCCL call itself)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return tile
     world = dist.get_world_size(group)
     bands = all_bands(H, world)

@@ -490,23 +490,25 @@ def _bench_module():
     return mod
 
 
-def test_bench_plain_start_launches_its_own_ranks():
-    """`python bench.py --gpus 2 ...` started as ONE plain process (no torch.distributed.run around it):
-    the parent starts two ranks, they rendezvous over gloo (no GPU here), the flags reach the ranks and
-    rank 0's line -- and only that line -- comes back on stdout."""
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_plain_start_launches_its_own_ranks(n):
+    """`python bench.py --gpus N ...` started as ONE plain process (no torch.distributed.run around it):
+    the parent starts N ranks (2, and the 8 of BASELINE configs[3]), they rendezvous over gloo (no GPU here), the flags
+    reach the ranks and rank 0's line -- and only that line -- comes back on stdout with every rank's row band."""
     import json
-    env = dict(os.environ, IDN_DIST_BACKEND="gloo")
+    env = dict(os.environ, IDN_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "3",
-                        "--size", "9", "--workload", "rendezvous"], env=env, capture_output=True, text=True, timeout=300)
+    size = 9 if n == 2 else 512
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "7", "--warmup", "3",
+                        "--size", str(size), "--workload", "rendezvous"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["backend"] == "gloo"
+    assert res["n_gpus"] == n and res["ranks"] == n and res["backend"] == "gloo"
     assert res["steps"] == 7 and res["warmup"] == 3
-    assert res["bands"] == [[0, 5], [5, 9]]
+    assert res["bands"] == ([[0, 5], [5, 9]] if n == 2 else [[64 * r, 64 * r + 64] for r in range(8)])
 
 
 def test_bench_launcher_propagates_a_failed_rank(tmp_path, capsys):

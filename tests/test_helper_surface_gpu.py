@@ -442,3 +442,47 @@ def test_bench_two_ranks_from_a_plain_start(dev):
     assert one.returncode == 0, one.stderr[-3000:]
     r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][-1])
     assert r1["n_gpus"] == 1 and r1["ranks"] == 1 and r1["config"]["rays_per_step"] == res["config"]["rays_per_step"]
+
+
+def test_bench_one_rank_rccl_communicator(dev):
+    """The RCCL branch of bench.py on the one GPU this box has: a ONE-rank "nccl" process group (device_id = this GPU,
+    HSA_ENABLE_IPC_MODE_LEGACY=0 as the multi-GPU launcher sets it) and the frame's `all_gather_into_tensor` issued through
+    it at world size 1 -- so backend initialisation, communicator creation and the collective call of the 8-GPU path
+    (BASELINE configs[3]; NeRFs/HeadNeRF/train/distribute_nerf.py:457-466 upstream) have run at least once."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               IDN_DIST_INIT_WORLD1="1", IDN_DIST_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("IDN_DIST_BACKEND", None)
+    p = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "96",
+                          "--no-cpu-baseline", "--no-side-mode"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(p.pid, signal.SIGKILL)
+        raise
+    assert p.returncode == 0, err[-3000:]
+    res = json.loads([ln for ln in out.splitlines() if ln.strip()][-1])
+    assert res["backend"] == "nccl" and res["ranks"] == 1 and res["n_gpus"] == 1
+    pr = res["per_rank"]
+    assert len(pr["render_ms"]) == 1 and pr["render_ms"][0] > 0 and pr["all_gather_ms"][0] > 0      # the collective ran and was timed
+    assert pr["step_ms_max"] <= res["ms_per_step"] * 1.05 + 1.0 and res["value"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus(dev):
+    """`--gpus 2` over RCCL on a one-GPU node: every rank says what is wrong before any communicator is built."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    for k in ("IDN_DIST_BACKEND", "IDN_FORCE_DEVICE"):
+        env.pop(k, None)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU node")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "exposes 1 GPU(s)" in p.stderr
