@@ -21,18 +21,6 @@ PARAM_KEYS = ([f"pts_linears.{i}.{k}" for i in range(8) for k in ("weight", "bia
               [f"views_linears.{i}.{k}" for i in range(3) for k in ("weight", "bias")] +
               ["alpha_linear.weight", "alpha_linear.bias", "rgb_linear.weight", "rgb_linear.bias"])
 
-_bwd_ws = {}
-
-
-def _workspace(nbytes, device):
-    key = str(device)
-    ws = _bwd_ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _bwd_ws[key] = ws
-    return ws
-
-
 def _grads_struct(grads):
     g = _lib.FaceNerfGrads()
     for i in range(8):
@@ -87,7 +75,7 @@ def _pass_bwd(net, aud, expr, latent, acts, raw, z, rays, bc, g_rgb, g_fg, g_lw,
     ptr = ops._ptr
     with ops._Launch(aud, expr, latent, acts, raw, z, rays, bc, g_rgb, g_fg, g_lw, g_acc, d_aud, d_latent,
                      *grads.values()) as L:
-        ws = _workspace(nbytes, z.device)
+        ws = ops._workspace(nbytes, z.device, L.stream)   # scratch of this (device, stream): two streams training on one GPU do not share it
         check(lib.idealnerf_pass_bwd(C.byref(ps), C.byref(gs), ptr(aud), ptr(expr), ptr(latent), ptr(acts),
                                      ptr(raw), ptr(z), ptr(rays), ptr(bc), n, S, ptr(g_rgb),
                                      ptr(g_fg), ptr(g_lw), ptr(g_acc), ptr(d_aud), ptr(d_latent), ws.data_ptr(),

@@ -236,10 +236,8 @@ int idealnerf_query_rays_train_fwd(const float* packed, const float* folded, int
     if (!packed || !folded || !rays || !z || !raw || !acts) return fail(IDN_EINVAL, "NULL pointer");
     const int64_t n = n_rays * n_samples;
     const int64_t p_pad = (n + 127) / 128 * 128;
-    if (p_pad > n)  // rows the kernel never writes must read as zero in the backward GEMMs
-        for (int i = 0; i < kActCount; ++i)
-            IDN_HIP_CHECK(hipMemsetAsync(acts + (size_t)act_off(i) * p_pad + (size_t)n * act_width(i), 0,
-                                         (size_t)(p_pad - n) * act_width(i) * sizeof(float), (hipStream_t)stream));
+    // (both activation-saving kernels write every row of the slab, the p_pad - n padding rows included -- they repeat the last
+    //  point, and their deltas are zero: tests/test_hip_parity.py::test_train_forward_defines_every_row_of_the_activation_slab)
     if (precision == IDN_PREC_BF16X6)
         return launch_mlp_bf16x6(packed, folded, nullptr, rays, z, nullptr, nullptr, n, n_samples, raw, (hipStream_t)stream, acts, p_pad);
     return launch_mlp_f32(packed, folded, nullptr, rays, z, nullptr, nullptr, n, n_samples, raw, (hipStream_t)stream,

@@ -126,7 +126,7 @@ static_assert(kActCols == 2560, "activation slab layout changed");
 // kernels share, so the backward delta chain loads one uint4 per lane and layer instead of gathering 16-byte
 // pieces of the saved activations.  Layer id 0..7 = a1..a8, 8..10 = v1..v3; entry
 // [id][wave tile = point / 32][lane] is a uint4 whose dword k holds tiles 2k, 2k+1: bit 31 - (16 (T & 1) + r)
-// = sign bit of the PRE-activation of register r of tile T (1 = the unit is off).
+// = 1 where the PRE-activation of register r of tile T is <= 0 (the unit is off; +0.0 counts as off, as in torch's relu backward).
 constexpr int kMaskLayers = 11;
 constexpr int kMaskFloatsPerPoint = kMaskLayers * 8;   // 2 lanes x 4 dwords per point and layer
 constexpr int kActColsAll = kActCols + kMaskFloatsPerPoint;

@@ -30,7 +30,7 @@ constexpr int f0(int l) { return kX6KFrags * plain_f0(l); }   // triples: 3 frag
 // k-step of the NEXT layer reads: it is complete after step (KS - 1, 0)), spread over the k-step
 constexpr int conv_slot(int nt, int w) { return nt == 1 ? 0 : 1 + (w * (nt - 1)) / 4; }
 
-// The training variant records a half tile where it is converted: the sign bits of the eight pre-activations into the
+// The training variant records a half tile where it is converted: the "unit off" bits of the eight pre-activations into the
 // layer's mask words, the ReLU applied in place, two 16-byte stores into this lane's row of the layer's activation
 // matrix (register 4 q + j of tile T is channel 32 T + 8 q + 4 h + j), then the split.
 struct Recorder {
@@ -42,10 +42,11 @@ template <int T, int HS, int W, bool SAVE>
 __device__ __forceinline__ void convert_word(f32x16& acc, KP& out, const Recorder& rec) {
     constexpr int r0 = 8 * HS + 2 * W;
     if constexpr (SAVE) {
-        rec.mk[T >> 1] = __builtin_amdgcn_alignbit(rec.mk[T >> 1], __float_as_uint(acc[r0]), 31);
-        rec.mk[T >> 1] = __builtin_amdgcn_alignbit(rec.mk[T >> 1], __float_as_uint(acc[r0 + 1]), 31);
         acc[r0] = relu1(acc[r0]);
         acc[r0 + 1] = relu1(acc[r0 + 1]);
+        // "unit off" = pre-activation <= 0 (+0.0 included, as torch's relu backward): the sign bit of the ReLU'd pattern - 1
+        rec.mk[T >> 1] = __builtin_amdgcn_alignbit(rec.mk[T >> 1], __float_as_uint(acc[r0]) - 1u, 31);
+        rec.mk[T >> 1] = __builtin_amdgcn_alignbit(rec.mk[T >> 1], __float_as_uint(acc[r0 + 1]) - 1u, 31);
         float w1, w2, w3;
         split3(acc[r0], acc[r0 + 1], w1, w2, w3);
         out.p[0][W] = w1;
@@ -94,6 +95,9 @@ __device__ __forceinline__ void prepare_half(f32x16& acc, KP& out, const Recorde
 template <int NT, int FROM, int TO, bool SAVE>
 struct Stores {
     static constexpr int at(int s, int t) {
+#ifdef IDN_TIMING_NO_ROW_STORES   // the timing-only build issues no row stores: nothing may be counted as in flight
+        return 0;
+#endif
         return (SAVE && s + 1 >= FROM && s + 1 < TO) ? (t == store_slot(NT, 0)) + (t == store_slot(NT, 1)) : 0;
     }
     // stores of the steps [i0, i1] of the layer (clipped to it)

@@ -424,12 +424,18 @@ __device__ __forceinline__ void input_features(const MlpArgs& a, long Pc, int h,
     }
 }
 
-// Sign bits of a tile's 16 pre-activations pushed into mask dword T / 2 (idn_internal.h "ReLU masks"):
-// one v_alignbit per value, (mk << 1) | (x >> 31).
+// "Unit off" bits of a tile's 16 pre-activations pushed into mask dword T / 2 (idn_internal.h "ReLU masks"): a unit is off
+// where its pre-activation is <= 0 -- exactly +0.0 included, as torch's relu backward (grad * (result > 0)) has it; the plain
+// sign bit would pass gradient through a unit that sits at +0.0 (a zero-weight, zero-bias layer).  x <= 0 <=> max_i32(bits, 0)
+// == 0 <=> the sign bit of max_i32(bits, 0) - 1; one v_alignbit per value pushes it: (mk << 1) | bit.
+__device__ __forceinline__ uint32_t off_bit_source(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return (uint32_t)((b > 0 ? b : 0) - 1);
+}
 template <int T>
 __device__ __forceinline__ void collect_signs(const f32x16& tile, uint32_t* mk) {
     static_for<16>([&](auto R) {
-        mk[T >> 1] = __builtin_amdgcn_alignbit(mk[T >> 1], __float_as_uint(tile[decltype(R)::value]), 31);
+        mk[T >> 1] = __builtin_amdgcn_alignbit(mk[T >> 1], off_bit_source(tile[decltype(R)::value]), 31);
     });
 }
 

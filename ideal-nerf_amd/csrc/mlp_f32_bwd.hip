@@ -159,7 +159,7 @@ struct MaskSide {
         const uint32_t w = mk[T >> 1];
         static_for<16>([&](auto R) {
             constexpr int r = decltype(R)::value, i = 16 * (T & 1) + r;
-            const int off = (int)(w << i) >> 31;   // all ones where the unit was off (sign bit of its pre-activation)
+            const int off = (int)(w << i) >> 31;   // all ones where the unit was off (its pre-activation <= 0)
             out[T][r] = __uint_as_float(__float_as_uint(out[T][r]) & ~(uint32_t)off);
         });
     }
@@ -471,7 +471,7 @@ struct MaskStoreSide {
         const uint32_t w = mk[T >> 1];
         static_for<16>([&](auto R) {
             constexpr int r = decltype(R)::value, i = 16 * (T & 1) + r;
-            const int off = (int)(w << i) >> 31;   // all ones where the unit was off (sign bit of its pre-activation)
+            const int off = (int)(w << i) >> 31;   // all ones where the unit was off (its pre-activation <= 0)
             O[T][r] = __uint_as_float(__float_as_uint(O[T][r]) & ~(uint32_t)off);
         });
     }

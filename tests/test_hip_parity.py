@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 NEAR, FAR = 0.5772005200386048, 1.1772005200386046
 RGB_TOL = 1e-4  # north_star: 1e-4 rel on RGB
+BF16X6_CODE = 4  # IDN_PREC_BF16X6
 
 
 @pytest.fixture(scope="module")
@@ -651,16 +652,64 @@ def test_train_step_matches_oracle_autograd_ragged(idn, dev):
             check_grads(net.face_nerf_fine.named_parameters(), pf, True, n_rays)
 
 
+def test_relu_backward_at_exactly_zero_matches_torch(idn, dev):
+    """A unit whose pre-activation is exactly +0.0 is OFF in torch's relu backward (grad * (result > 0)).  pts_linears.3
+    with zero weights and zero bias puts all 256 of its pre-activations at +0.0 for every point: no gradient may pass
+    -- d(pts_linears.3.bias) = 0 and everything upstream of it gets zero gradient -- exactly as the reference's autograd
+    has it (the ReLU masks record "pre-activation <= 0", not the sign bit)."""
+    from idealnerf_amd.helper import img2mse
+    net, syn = _train_net(idn, dev)
+    with torch.no_grad():
+        for m in (net.face_nerf_coarse, net.face_nerf_fine):
+            m.pts_linears[3].weight.zero_()
+            m.pts_linears[3].bias.zero_()
+    rs = np.random.RandomState(3)
+    ro, rd = oracle.camera_rays(32, 32, syn["focal"], syn["c2w"])
+    sel = T(rs.choice(1024, size=64, replace=False))
+    rays, bc = oracle.ray_records(ro, rd, NEAR, FAR)[sel].contiguous(), syn["bc"].reshape(-1, 3)[sel].contiguous()
+    tgt = T(rs.uniform(0, 1, size=(64, 3)).astype(np.float32))
+    dims = oracle.facenerf_dims()
+    pc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.face_nerf_coarse.state_dict().items()}
+    pf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.face_nerf_fine.state_dict().items()}
+    aud_o, lat_o = syn["aud"].clone().requires_grad_(True), syn["latent"].clone().requires_grad_(True)
+    loss_o, _ = oracle.train_loss(oracle.render_rays(rays, bc, pc, pf, aud_o, syn["expr"], lat_o, dims=dims), tgt, lat_o)
+    loss_o.backward()
+    assert float(pc["pts_linears.3.bias"].grad.abs().max()) == 0.0 and float(pc["pts_linears.1.weight"].grad.abs().max()) == 0.0   # torch: off
+    aud, lat = syn["aud"].to(dev).requires_grad_(True), syn["latent"].to(dev).requires_grad_(True)
+    ret = net.render_rays(rays.to(dev), bc.to(dev), aud, syn["c2w"], lat, syn["expr"].to(dev))
+    loss = img2mse(ret["rgb_map"], tgt.to(dev)) + img2mse(ret["rgb0"], tgt.to(dev)) + 10 * (torch.norm(lat) * 0.0005)
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) < 1e-5 * abs(float(loss_o))
+    for m, ref in ((net.face_nerf_coarse, pc), (net.face_nerf_fine, pf)):
+        named = dict(m.named_parameters())
+        for k in ("pts_linears.3.bias", "pts_linears.3.weight", "pts_linears.2.weight", "pts_linears.0.weight"):
+            assert float(named[k].grad.abs().max()) == 0.0, k          # nothing passes a unit that sits at +0.0
+        assert float(named["pts_linears.4.weight"].grad.abs().max()) == 0.0      # its input is relu(0) = 0 for every point
+        for k in ("pts_linears.4.bias", "pts_linears.5.weight", "pts_linears.7.weight", "rgb_linear.weight"):
+            assert l2_err(named[k].grad, ref[k].grad) < GRAD_L2_FINE, k
+    # the conditioning still reaches the loss through pts_linears.5's re-injected input
+    assert l2_err(aud.grad, aud_o.grad) < GRAD_L2_FINE
+
+
 def test_training_on_the_fp32_pipe_still_passes_the_gradient_tests(dev):
     """The fallback arm: IDN_TRAIN_PRECISION=f32 (forward on the fp32 MFMA kernel) + IDN_BACKWARD_PIPE=f32 (fp32 delta
     chain and fp32 256 x 256 GEMMs) are read once per process, so the gradient tests run again in a fresh one."""
     import subprocess
     import sys
+    import signal
     env = dict(os.environ, IDN_TRAIN_PRECISION="f32", IDN_BACKWARD_PIPE="f32")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "train_step_gradients_golden or backward_kernels_vs_fp64 or train_step_matches_oracle_autograd_ragged"],
-                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    # its own process group and a limit below the suite's: a child that hangs is killed by group id, it does not keep the GPU
+    child = subprocess.Popen([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                              "train_step_gradients_golden or backward_kernels_vs_fp64 or train_step_matches_oracle_autograd_ragged or exactly_zero"],
+                             env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        out, err = child.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        os.killpg(child.pid, signal.SIGKILL)
+        child.wait()
+        pytest.fail("the fp32-pipe child run did not finish within 240 s")
+    assert child.returncode == 0 and "4 passed" in out, out[-3000:] + err[-2000:]
 
 
 def test_train_step_is_bit_reproducible_at_bench_scale(idn, dev):
@@ -1442,11 +1491,24 @@ def test_train_forward_defines_every_row_of_the_activation_slab(idn, dev):
     z = idn.ops.coarse_depths(rays, torch.linspace(0.0, 1.0, S).to(dev))
     folded = net.folded_bias(syn["aud"].to(dev), syn["expr"].to(dev), syn["latent"].to(dev))
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=dev)
-    acts = torch.full((lib.idealnerf_train_acts_floats(n * S),), float("nan"), dtype=torch.float32, device=dev)
-    rc = lib.idealnerf_query_rays_train_fwd(net.packed_weights("f32").data_ptr(), folded.data_ptr(), 0, rays.data_ptr(),
-                                            z.data_ptr(), n, S, raw.data_ptr(), acts.data_ptr(),
-                                            torch.cuda.current_stream().cuda_stream)
-    assert rc == 0, lib.idealnerf_last_error()
+    # both activation-saving kernels (the six-piece bf16 one first, the fp32 one last: its slab is examined below)
+    for prec_name, code in (("bf16x6", BF16X6_CODE), ("f32", 0)):
+        acts = torch.full((lib.idealnerf_train_acts_floats(n * S),), float("nan"), dtype=torch.float32, device=dev)
+        rc = lib.idealnerf_query_rays_train_fwd(net.packed_weights(prec_name).data_ptr(), folded.data_ptr(), code, rays.data_ptr(),
+                                                z.data_ptr(), n, S, raw.data_ptr(), acts.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.idealnerf_last_error()
+        assert bool(torch.isfinite(acts[:256 * 2560]).all()) and bool(torch.isfinite(raw).all()), prec_name
+        if prec_name == "bf16x6":
+            acts6 = acts
+    assert rel_err(acts6[:256 * 2560], acts[:256 * 2560]) < 1e-5       # the two kernels save the same activations
+    # ... and the same ReLU masks (a8-wide layers: four dwords per lane, the 128-wide ones: two; a pre-activation within
+    # rounding of zero may fall on either side in the two arithmetics)
+    m6, m32 = (a[256 * 2560:].view(torch.int32).reshape(11, 8, 64, 4) for a in (acts6, acts))
+    diff = (m6 ^ m32)
+    diff[8:, :, :, 2:] = 0
+    bits = sum(int(((diff >> b) & 1).sum()) for b in range(32))
+    assert bits <= 4, bits
     assert acts.numel() == 256 * (2560 + 88)   # 185 points -> p_pad = 256 rows of 2560 columns + 88 floats of ReLU mask bits
     assert bool(torch.isfinite(acts[:256 * 2560]).all()) and bool(torch.isfinite(raw).all())   # the tail is bit masks, not floats
     # the packed ReLU masks say exactly which saved activations are positive: layer a3 (id 2), every point and channel
