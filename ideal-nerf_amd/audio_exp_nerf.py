@@ -52,9 +52,12 @@ class Network(nn.Module):
         batch_rays, target_s, bg_img, auds, raw_img, pose, expr, latent_code, index = x
         dev = self.face_nerf_coarse.alpha_linear.weight.device
         sq = lambda t: torch.squeeze(t).to(device=dev, dtype=torch.float32)
-        # the camera matrix is read on the host (it becomes kernel arguments): keep the loader's CPU copy
-        # rather than bouncing it through the device, which would stall the host on the stream every frame
-        pose_host = torch.squeeze(pose).detach().to(device="cpu", dtype=torch.float32)
+        # Full-frame rendering reads the camera matrix on the host (it becomes kernel arguments): keep the loader's CPU copy
+        # rather than bouncing it through the device.  Training never needs it -- and a pose that already lives on the device
+        # must not be fetched there: the device-to-host copy would block the host until the GPU has drained its queue, once
+        # per step, and the step's ~100 small launches would then run with the host never ahead (measured: 1.2 ms of idle GPU
+        # per 16 ms step, tools/train_timeline.py / train_host_time.py).
+        pose_host = None if self.training is True else torch.squeeze(pose).detach().to(device="cpu", dtype=torch.float32)
         batch_rays, bg_img, auds, pose, expr = sq(batch_rays), sq(bg_img), sq(auds), sq(pose), sq(expr)
         latent_code = torch.squeeze(latent_code).to(dev)
         index = int(index)
@@ -80,7 +83,7 @@ class Network(nn.Module):
             aud_feature = self.ds_aud_net(aud_feature.unsqueeze(0) if aud_feature.dim() == 2 else aud_feature)
         if args.dim_expr > 0:
             expr_feature = expr
-        render_poses = None if self.training is True else pose_host[:3, :4]
+        render_poses = None if pose_host is None else pose_host[:3, :4]
         return self.render_dynamic_face(H=raw_img.shape[1], W=raw_img.shape[1], focal=self.focal, expr=expr_feature,
                                         poses=pose, latent_code=latent_code, render_poses=render_poses,
                                         chunk=args.chunk, near=self.near, far=self.far, rays=batch_rays,
