@@ -113,8 +113,10 @@ constexpr int kFirstYoungStep = 5;   // in-slice step from which a wave's stores
 // of its first step (unless the layer starts on a slice boundary).  side(ic<s>, ic<t>, Bn) runs inside step (s, t) and
 // fills Bn, the pieces of the NEXT k-step (of this layer, or -- in the layer's last k-step -- of the next layer, along
 // with that layer's biases).  ST: the row stores the side work issues (training), see Stores.
-template <int F0, int NT, int KS, int OPEN_YOUNGER, class ST, class Side, class Hook>
-__device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WStream6& ws, FragReader& fr, f32x4 (&pref)[3], Hook&& after_open) {
+template <int F0, int NT, int KS, int OPEN_YOUNGER, class ST, class Side, class Hook, class WS>
+__device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WS& ws, FragReader& fr, f32x4 (&pref)[3], Hook&& after_open) {
+    static_assert(WS::kSlotsT == 2 || (OPEN_YOUNGER == 0 && ST::in_steps(0, NT * KS - 1, NT * KS) == 0),
+                  "the deeper ring's counted waits are written for a kernel that stores nothing (inference)");
     constexpr int NP = NT * KS;
     constexpr int kSliceSteps = kX6SliceFrags / kX6KFrags;
     constexpr bool LAST = (F0 + kX6KFrags * NP == kX6UsedFrags);
@@ -122,7 +124,7 @@ __device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WStream
     if constexpr (F0 % kX6SliceFrags == 0) {
         ws.template open_slice<OPEN_YOUNGER>();   // (training: the row stores of the layer before stay in flight)
         after_open();
-        static_for<3>([&](auto Q) { pref[decltype(Q)::value] = issue6<F0 + decltype(Q)::value>(fr); });
+        static_for<3>([&](auto Q) { pref[decltype(Q)::value] = issue6<F0 + decltype(Q)::value, WS>(fr); });
         retire3<0>(pref);
     } else {
         static_assert(std::is_same_v<std::decay_t<Hook>, NoHook>, "a hook needs a layer that starts on a slice boundary");
@@ -137,7 +139,7 @@ __device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WStream
         constexpr bool has_next = !(LAST && pi + 1 == NP);
         f32x4 n[3] = {a[0], a[1], a[2]};
         if constexpr (!next_crosses && has_next) {
-            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value>(fr); });
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value, WS>(fr); });
             if constexpr (pi > 0) retire3<3>(a);   // (step 0's arrived retired)
         } else {
             if constexpr (pi > 0) retire3<0>(a);
@@ -156,12 +158,15 @@ __device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WStream
             // the slice that ends with this step: its steps from kFirstYoungStep on (those of them that belong to this layer)
             constexpr int y = ST::in_steps(pi - (kSliceSteps - 1) + kFirstYoungStep, pi, NP);
             ws.template open_slice<y>();
-            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value>(fr); });
+            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value, WS>(fr); });
         }
         a[0] = n[0];
         a[1] = n[1];
         a[2] = n[2];
         if constexpr (t == NT - 1) B = Bn;
+        // a step's side work stays in its step (mlp_x6.h, cvt_pk_bf16: the asm conversions must keep their distance from the MFMAs
+        // that read their results, which are those of the NEXT k-step)
+        __builtin_amdgcn_sched_barrier(0);
     });
     // hand over retired fragments (those of the next layer's first step, when this layer ends inside a slice)
     if constexpr (!LAST && (F0 + kX6KFrags * NP) % kX6SliceFrags != 0) retire3<0>(a);
@@ -195,7 +200,8 @@ template <int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
-    float* bias_s = reinterpret_cast<float*>(smem + kX6RingFrags * kFragBytes);
+    using WS = std::conditional_t<SAVE, WStream6, WStream6x3>;   // inference: three ring slots (pieces fetched two slices ahead)
+    float* bias_s = reinterpret_cast<float*>(smem + WS::kSlotsT * kX6SliceFrags * kFragBytes);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
     __syncthreads();  // the bias block is read (by other waves) before the first slice barrier
 
     Diag dg;
-    WStream6 ws;
+    WS ws;
     ws.dg = &dg;
 #ifdef IDN_TIMING_STREAM_WRAP   // timing-only (wrong results): the stream wraps after this many slices -- is anything left of the L2 question?
     ws.init(a.wstream, IDN_TIMING_STREAM_WRAP, ring, tid, wave);
@@ -219,6 +225,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
     FragReader fr;
     fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
     fr.addr1 = fr.addr0 + 64 * kFragBytes;
+    fr.addr2 = fr.addr0 + 128 * kFragBytes;
     const float* bias_h = bias_s + 4 * h;
     const long ntiles = (a.n_points + 127) >> 7;
 
@@ -442,15 +449,17 @@ int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, 
     if (acts && (x || pts)) return fail(IDN_EUNSUPPORTED, "the activation-saving forward takes rays");
     static LaunchSetup setup;
     int num_cu = 0;
+    constexpr int kLdsInfer = x6::mlp_lds6<x6::WStream6x3>(), kLdsTrain = x6::mlp_lds6<x6::WStream6>();
+    static_assert(kLdsInfer <= 160 * 1024, "LDS per CU");
     if (int e = setup.get([]() -> int {
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeRays, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, x6::kMlpLds6));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsInfer));
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeRays, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, x6::kMlpLds6));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTrain));
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeX, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, x6::kMlpLds6));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsInfer));
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModePts, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, x6::kMlpLds6));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsInfer));
             return IDN_OK;
         }, &num_cu))
         return e;
@@ -459,13 +468,13 @@ int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, 
     MlpArgs a{packed, folded, x, rays, z, pts, dirs, (long)n_points, n_samples, raw, acts, (long)p_pad};
     ProfScope prof(s, n_points, acts ? IDN_PROF_MLP_FWD_SAVE_X6 : IDN_PROF_MLP_FWD);
     if (x)
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeX, false>), dim3(grid), dim3(256), x6::kMlpLds6, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeX, false>), dim3(grid), dim3(256), kLdsInfer, s, a);
     else if (pts)
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModePts, false>), dim3(grid), dim3(256), x6::kMlpLds6, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModePts, false>), dim3(grid), dim3(256), kLdsInfer, s, a);
     else if (acts)
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, true>), dim3(grid), dim3(256), x6::kMlpLds6, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, true>), dim3(grid), dim3(256), kLdsTrain, s, a);
     else
-        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, false>), dim3(grid), dim3(256), x6::kMlpLds6, s, a);
+        hipLaunchKernelGGL((x6::mlp_bf16x6_kernel<kModeRays, false>), dim3(grid), dim3(256), kLdsInfer, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

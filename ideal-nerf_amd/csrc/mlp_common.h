@@ -70,15 +70,16 @@ struct Diag {};
 // ---------------------------------------------------------------------------
 constexpr int kAhead = kRingSlots - 1;  // slices in flight ahead of the consumer
 
-template <int NW, int SLICE_FRAGS = kSliceFrags>
+template <int NW, int SLICE_FRAGS = kSliceFrags, int SLOTS = kRingSlots>
 struct WStreamT {
     static constexpr int kSliceFragsT = SLICE_FRAGS;               // fragments per ring slot (64; the six-piece streams: 48)
     static constexpr int kSliceBytesT = SLICE_FRAGS * kFragBytes;
+    static constexpr int kSlotsT = SLOTS;                          // ring slots: slices are fetched SLOTS - 1 ahead of their use
+    static constexpr int kAheadT = SLOTS - 1;
     static constexpr int kPieceBytes = NW * kFragBytes;
     static constexpr int kPieces = kSliceBytesT / kPieceBytes;     // pieces per slice
-    static constexpr int kVmcntOpen = (kAhead - 1) * kPieces;      // younger pieces allowed in flight at a barrier
+    static constexpr int kVmcntOpen = (kAheadT - 1) * kPieces;     // younger pieces allowed in flight at a barrier
     static_assert(kSliceBytesT % kPieceBytes == 0 && kPieces % 4 == 0, "a wave's pieces come in groups of four (one M0 / scalar offset per group)");
-    static_assert(kVmcntOpen == 0 || kVmcntOpen == 8 || kVmcntOpen == 16, "add the s_waitcnt literal below");
 
     Diag* dg;
     __amdgpu_buffer_rsrc_t rsrc;
@@ -99,7 +100,7 @@ struct WStreamT {
         next_slice = 0;
         num_slices = slices;
         ring_wave = ring + wave * (kPieces * kFragBytes);
-        static_for<kAhead>([&](auto S_) { issue_rest<decltype(S_)::value, 0>(); });  // slices 0 .. kAhead-1
+        static_for<kAheadT>([&](auto S_) { issue_rest<decltype(S_)::value, 0>(); });  // slices 0 .. kAheadT-1
     }
     __device__ __forceinline__ void advance() {
         soff += kSliceBytesT;
@@ -127,10 +128,7 @@ struct WStreamT {
     __device__ __forceinline__ void open_slice() {
         DIAG_BEGIN(*dg);
         static_assert(kVmcntOpen + YOUNGER <= 63, "vmcnt is a 6-bit field");
-        if constexpr (YOUNGER > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kVmcntOpen + YOUNGER) : "memory");
-        else if constexpr (kVmcntOpen == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if constexpr (kVmcntOpen == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kVmcntOpen + YOUNGER) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         DIAG_END(*dg, kDgBarrier);
@@ -139,13 +137,13 @@ struct WStreamT {
     template <int F>
     __device__ __forceinline__ void step_piece() {
         constexpr int jpos = (F % SLICE_FRAGS) / 2;
-        constexpr int slot = (F / SLICE_FRAGS + kAhead) % kRingSlots;
+        constexpr int slot = (F / SLICE_FRAGS + kAheadT) % SLOTS;
         if constexpr (jpos < kPieces) issue_piece<slot, jpos>();
     }
     // the same by position: piece JPOS (if the slice has that many) of the slice fetched while slice F / SLICE_FRAGS is consumed
     template <int F, int JPOS>
     __device__ __forceinline__ void step_piece_at() {
-        constexpr int slot = (F / SLICE_FRAGS + kAhead) % kRingSlots;
+        constexpr int slot = (F / SLICE_FRAGS + kAheadT) % SLOTS;
         if constexpr (JPOS < kPieces) issue_piece<slot, JPOS>();
     }
 };
@@ -162,6 +160,7 @@ using WStream = WStreamT<4>;
 // ---------------------------------------------------------------------------
 struct FragReader {
     uint32_t addr0, addr1;  // LDS byte address of this lane's 16 bytes in fragment 0 / fragment 64
+    uint32_t addr2;         // ... / fragment 128 (rings longer than 128 fragments: the three-slot six-piece ring)
     f32x4 pref0, pref1;     // fragment pair issued ahead of its consumer (layer / slice start)
 
     template <int F, int RING_FRAGS = kRingFrags>
@@ -170,8 +169,10 @@ struct FragReader {
         f32x4 v;
         if constexpr (fr < 64)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr0), "n"(fr * kFragBytes) : "memory");
-        else
+        else if constexpr (fr < 128)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr1), "n"((fr - 64) * kFragBytes) : "memory");
+        else
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr2), "n"((fr - 128) * kFragBytes) : "memory");
         return v;
     }
     // all but the newest `Newer` LDS reads of this wave have completed => v0, v1 are valid

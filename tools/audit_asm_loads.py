@@ -17,8 +17,8 @@ v_accvgpr_read always sits in between, with VGPR accumulators (two waves per SIM
 registers) an asm ReLU read the result early and returned garbage.
 
 Third check, same walk: a counted `s_waitcnt vmcnt(N)` in front of a slice barrier (the training kernels
-keep their row stores in flight across it) must have at least N vector-memory operations between it and the
-last LDS-DMA piece on every path.
+keep their row stores in flight across it, the three-slot inference ring the next slice's pieces) must have at
+least N vector-memory operations between it and the last LDS-DMA piece of the slice it opens, on every path.
 
 Usage: audit_asm_loads.py file.s [kernel-name-substring]
 """
@@ -149,56 +149,84 @@ def audit_inflight(insts, labels, name):
     return bad
 
 
-def audit_counted_slice_waits(insts, labels, name):
+THREE_SLOT_RING = re.compile(r"mlp_bf16x6_kernelILi\dELb0E")   # the inference six-piece forward: pieces are fetched TWO slices ahead
+
+
+def audit_asm_valu_to_mfma(insts, name, window=8):
+    """Fourth check, straight-line: an MFMA reading (as A / B operand) a VGPR that an inline-asm vector instruction wrote fewer
+    than `window` instructions earlier.  The recogniser inserts no wait states for what it cannot see: a v_cvt_pk_bf16_f32
+    in asm followed two MFMAs later by the MFMA that read its result returned garbage (round 3)."""
+    bad, recent = 0, []
+    for idx, (no, code, in_asm) in enumerate(insts):
+        recent = [(r, i, n0) for r, i, n0 in recent if idx - i < window]
+        if code.startswith('v_mfma'):
+            ops = code.split(None, 1)[1].split(',')
+            srcs = regs(','.join(ops[1:3]))          # srcA, srcB
+            for r, i, n0 in recent:
+                if r & srcs:
+                    bad += 1
+                    print(f"  {name}: line {no}: `{code}` reads a register an inline-asm vector instruction wrote {idx - i} instructions earlier (line {n0})")
+                    break
+        elif in_asm and code.startswith('v_') and not code.startswith('v_mfma'):
+            recent.append((regs(code.split(None, 1)[1].split(',')[0]), idx, no))
+    return bad
+
+
+def audit_counted_slice_waits(insts, labels, name, slots=2):
     """Third check: the slice barriers of the MLP kernels wait for this wave's LDS-DMA pieces (`buffer_load ... lds`) of
-    the slice being opened with `s_waitcnt vmcnt(N)` + `s_barrier`.  vmcnt retires in issue order, so N > 0 is only
-    right if at least N vector-memory operations (the training kernels' row stores) were issued AFTER the last piece on
-    every path that reaches the wait -- else the wait can pass with a piece still in flight.  State = operations since
-    the last piece (saturating); every (instruction, state) pair is explored once, branches and loops followed."""
+    the slice being opened with `s_waitcnt vmcnt(N)` + `s_barrier`.  vmcnt retires in issue order, so the N youngest
+    vector-memory operations may only stay in flight if every one of them was issued AFTER the last piece of the slice being
+    opened -- else the wait can pass with such a piece still in flight.  In a two-slot ring that piece is the last one
+    issued before the wait (the younger operations are the training kernels' row stores); in a three-slot ring the slice
+    being opened was fetched a slice earlier, so it is the last piece issued before the PREVIOUS slice barrier (and the
+    twelve pieces issued since are the next slice's, legitimately in flight).  State = operations since either piece
+    (saturating); every (instruction, state) triple is explored once, branches and loops followed."""
     bad, reported, seen = 0, set(), set()
-    work = [(0, 64)]          # nothing is known at kernel entry: no piece has been issued yet
+    work = [(0, 64, 64)]          # nothing is known at kernel entry: no piece has been issued yet
     steps = 0
-    while work and steps < 2_000_000:
-        idx, since = work.pop()
+    while work and steps < 4_000_000:
+        idx, since, since_prev = work.pop()
         while idx < len(insts):
-            if (idx, since) in seen:
+            if (idx, since, since_prev) in seen:
                 break
-            seen.add((idx, since))
+            seen.add((idx, since, since_prev))
             steps += 1
             no, code, in_asm = insts[idx]
             op = code.split()[0] if code else ''
             if op.startswith(('buffer_load', 'global_load', 'scratch_load', 'flat_load')) and code.rstrip().endswith(' lds'):
-                since = 0                                   # an LDS-DMA piece
+                since, since_prev = 0, min(since_prev + 1, 64)   # an LDS-DMA piece
             elif op.startswith(('buffer_', 'global_', 'scratch_', 'flat_')) and not op.startswith('buffer_wbinvl') and not op.startswith('buffer_inv'):
-                since = min(since + 1, 64)
+                since, since_prev = min(since + 1, 64), min(since_prev + 1, 64)
             elif op == 's_waitcnt':
                 m = re.search(r'vmcnt\((\d+)\)', code)
-                if m and int(m.group(1)) > 0 and in_asm:
-                    nxt = next((c for _, c, a in insts[idx + 1: idx + 3] if c), '')
-                    if nxt.startswith('s_barrier') and since < int(m.group(1)) and (no,) not in reported:
+                nxt = next((c for _, c, a in insts[idx + 1: idx + 3] if c), '')
+                if m and in_asm and nxt.startswith('s_barrier'):
+                    n, have = int(m.group(1)), (since_prev if slots == 3 else since)
+                    if n > 0 and have < n and (no,) not in reported:
                         reported.add((no,))
                         bad += 1
-                        print(f"  {name}: line {no}: `{code}` before a slice barrier, but only {since} vector-memory operations "
-                              f"were issued since the last LDS-DMA piece on some path: a piece may still be in flight")
+                        print(f"  {name}: line {no}: `{code}` before a slice barrier, but only {have} vector-memory operations "
+                              f"were issued since the last LDS-DMA piece of the slice it opens ({slots}-slot ring) on some path: a piece may still be in flight")
+                    since_prev = since        # the last piece so far precedes this barrier
             if code.startswith('s_endpgm'):
                 break
             if code.startswith('s_branch') or code.startswith('s_cbranch'):
                 tgt = labels.get(code.split()[1])
                 if tgt is not None:
-                    work.append((tgt, since))
+                    work.append((tgt, since, since_prev))
                 if code.startswith('s_branch'):
                     break
             idx += 1
     return bad
 
 
-def audit(lines, name):
+def audit(lines, name, full_name=None):
     insts, labels = parse(lines)
-    bad = audit_inflight(insts, labels, name) + audit_mfma_to_asm_valu(insts, name)
+    bad = audit_inflight(insts, labels, name) + audit_mfma_to_asm_valu(insts, name) + audit_asm_valu_to_mfma(insts, name)
     # the two-slot weight ring of the MLP / delta-chain kernels: every barrier needs ALL of the wave's pieces.  (The dW GEMM's
     # three-buffer tiles leave the pieces of the NEXT chunk in flight on purpose: there the younger operations are pieces.)
     if "mlp_" in name or "delta_chain" in name:
-        bad += audit_counted_slice_waits(insts, labels, name)
+        bad += audit_counted_slice_waits(insts, labels, name, 3 if THREE_SLOT_RING.search(full_name or name) else 2)
     return bad
 
 
@@ -214,7 +242,7 @@ def main():
             cur.append((no, ln))
             if 's_endpgm' in ln:
                 if want in name and 'kernel' in name:
-                    b = audit(cur, name[:40])
+                    b = audit(cur, name[:40], name)
                     print(f"{name[:60]}: {b} suspicious touches")
                     total += b
                 name = None
