@@ -57,10 +57,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// (lo half, hi half) = (bf16(x0), bf16(x1)), round to nearest even
+// (lo half, hi half) = (bf16(x0), bf16(x1)), round to nearest even.  The two wait states behind it are part of the
+// instruction as far as this kernel is concerned: an MFMA that reads a register a vector instruction wrote needs them
+// (tools/valu_mfma_hazard_ubench.hip), the hazard recogniser does not see inside asm, and the plain-bf16 kernel had four
+// places per pass where the conversion, `s_nop 0` and the MFMA reading its result followed each other -- the MFMA then
+// took the register's OLD contents for two of its sixteen channels (found by tools/audit_asm_loads.py's fourth check in
+// round 3; inside the plain-bf16 mode's 6.5e-3 it had gone unnoticed).
 __device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
     unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(x0), "v"(x1));
     return r;
 }
 // one packed word of the hi part and of the lo part from two fp32 values

@@ -26,10 +26,6 @@ namespace x6 {
 
 constexpr int f0(int l) { return kX6KFrags * plain_f0(l); }   // triples: 3 fragments per step (plain_f0 counts steps)
 
-// tile-step at which word W (of 4) of the next k-step's pieces is produced: after tile 0 (whose accumulator the first
-// k-step of the NEXT layer reads: it is complete after step (KS - 1, 0)), spread over the k-step
-constexpr int conv_slot(int nt, int w) { return nt == 1 ? 0 : 1 + (w * (nt - 1)) / 4; }
-
 // The training variant records a half tile where it is converted: the "unit off" bits of the eight pre-activations into the
 // layer's mask words, the ReLU applied in place, two 16-byte stores into this lane's row of the layer's activation
 // matrix (register 4 q + j of tile T is channel 32 T + 8 q + 4 h + j), then the split.
@@ -68,10 +64,6 @@ __device__ __forceinline__ void store_quad(const f32x16& acc, const Recorder& re
     *reinterpret_cast<f32x4*>(rec.row + 32 * T + 8 * Q) = f32x4{acc[4 * Q], acc[4 * Q + 1], acc[4 * Q + 2], acc[4 * Q + 3]};
 }
 
-// tile-steps at which the two row stores of a prepared half tile are issued (training): behind the words of their quad, and
-// in an 8-tile layer at tile-steps 6 and 7, i.e. AFTER the twelve LDS-DMA pieces a wave issues in steps 0..5 of a slice
-constexpr int store_slot(int nt, int q) { return nt >= 8 ? nt - 2 + q : conv_slot(nt, 3); }
-
 // The side work of step (.., t) of a k-step of NT tiles that prepares half tile (T, HS) of `acc` as the next k-step's
 // pieces: words at conv_slot(NT, 0..3); training: the two row stores of the half tile at store_slot(NT, 0 / 1).
 template <int NT, int t, int T, int HS, bool SAVE>
@@ -86,101 +78,6 @@ __device__ __forceinline__ void prepare_half(f32x16& acc, KP& out, const Recorde
         if constexpr (t == store_slot(NT, 1)) store_quad<T, 2 * HS + 1>(acc, rec);
     }
 }
-// Row stores issued by step (s, t) of a layer whose k-steps [from, to) each prepare a half tile (training; `to` may be KS + 1:
-// the layer's last k-step prepares the next layer's first).  On gfx9 stores count in vmcnt, vmcnt retires in issue order, and
-// a slice barrier waits for the wave's pieces of the next slice -- which are issued in steps 0..5 of a slice.  The stores
-// issued from step 5 of a slice on are therefore YOUNGER than those pieces and may stay in flight across the barrier: the
-// barrier waits vmcnt(their number) instead of vmcnt(0).  The number is counted from this table at compile time -- never
-// more than were issued (tools/audit_asm_loads.py checks the compiled ISA).
-template <int NT, int FROM, int TO, bool SAVE>
-struct Stores {
-    static constexpr int at(int s, int t) {
-#ifdef IDN_TIMING_NO_ROW_STORES   // the timing-only build issues no row stores: nothing may be counted as in flight
-        return 0;
-#endif
-        return (SAVE && s + 1 >= FROM && s + 1 < TO) ? (t == store_slot(NT, 0)) + (t == store_slot(NT, 1)) : 0;
-    }
-    // stores of the steps [i0, i1] of the layer (clipped to it)
-    static constexpr int in_steps(int i0, int i1, int np) {
-        int n = 0;
-        for (int i = (i0 < 0 ? 0 : i0); i <= i1 && i < np; ++i) n += at(i / NT, i % NT);
-        return n;
-    }
-};
-constexpr int kFirstYoungStep = 5;   // in-slice step from which a wave's stores are younger than its pieces of the next slice
-
-// One layer, K-major.  On entry O[0..NT) hold the layer's biases, B the pieces of its k-step 0, `pref` the fragments
-// of its first step (unless the layer starts on a slice boundary).  side(ic<s>, ic<t>, Bn) runs inside step (s, t) and
-// fills Bn, the pieces of the NEXT k-step (of this layer, or -- in the layer's last k-step -- of the next layer, along
-// with that layer's biases).  ST: the row stores the side work issues (training), see Stores.
-template <int F0, int NT, int KS, int OPEN_YOUNGER, class ST, class Side, class Hook, class WS>
-__device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WS& ws, FragReader& fr, f32x4 (&pref)[3], Hook&& after_open) {
-    static_assert(WS::kSlotsT == 2 || (OPEN_YOUNGER == 0 && ST::in_steps(0, NT * KS - 1, NT * KS) == 0),
-                  "the deeper ring's counted waits are written for a kernel that stores nothing (inference)");
-    constexpr int NP = NT * KS;
-    constexpr int kSliceSteps = kX6SliceFrags / kX6KFrags;
-    constexpr bool LAST = (F0 + kX6KFrags * NP == kX6UsedFrags);
-    static_assert(F0 % kX6KFrags == 0, "triples");
-    if constexpr (F0 % kX6SliceFrags == 0) {
-        ws.template open_slice<OPEN_YOUNGER>();   // (training: the row stores of the layer before stay in flight)
-        after_open();
-        static_for<3>([&](auto Q) { pref[decltype(Q)::value] = issue6<F0 + decltype(Q)::value, WS>(fr); });
-        retire3<0>(pref);
-    } else {
-        static_assert(std::is_same_v<std::decay_t<Hook>, NoHook>, "a hook needs a layer that starts on a slice boundary");
-    }
-    f32x4 a[3] = {pref[0], pref[1], pref[2]};
-    KP Bn = B;
-    static_for<NP>([&](auto PI) {
-        constexpr int pi = decltype(PI)::value;
-        constexpr int s = pi / NT, t = pi % NT;
-        constexpr int f = F0 + kX6KFrags * pi;
-        constexpr bool next_crosses = ((f + kX6KFrags) % kX6SliceFrags == 0);
-        constexpr bool has_next = !(LAST && pi + 1 == NP);
-        f32x4 n[3] = {a[0], a[1], a[2]};
-        if constexpr (!next_crosses && has_next) {
-            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value, WS>(fr); });
-            if constexpr (pi > 0) retire3<3>(a);   // (step 0's arrived retired)
-        } else {
-            if constexpr (pi > 0) retire3<0>(a);
-        }
-        step_pieces6<f>(ws);
-        // (an order of the six products that changes fewer MFMA operands between consecutive instructions -- w3a1, w1a1, w2a1,
-        //  w2a2, w1a2, w1a3 and the reverse in odd tile-steps -- measured -0.5 %: profiles/r03_ab_x6_product_order.log)
-        O[t] = mfma_bf(a[0], B.p[0], O[t]);   // w1 a1
-        O[t] = mfma_bf(a[0], B.p[1], O[t]);   // w1 a2
-        O[t] = mfma_bf(a[1], B.p[0], O[t]);   // w2 a1
-        side(ic<s>{}, ic<t>{}, Bn);           // the next k-step's pieces, in this one's MFMA shadow
-        O[t] = mfma_bf(a[1], B.p[1], O[t]);   // w2 a2
-        O[t] = mfma_bf(a[0], B.p[2], O[t]);   // w1 a3
-        O[t] = mfma_bf(a[2], B.p[0], O[t]);   // w3 a1
-        if constexpr (next_crosses && pi + 1 < NP) {
-            // the slice that ends with this step: its steps from kFirstYoungStep on (those of them that belong to this layer)
-            constexpr int y = ST::in_steps(pi - (kSliceSteps - 1) + kFirstYoungStep, pi, NP);
-            ws.template open_slice<y>();
-            static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value, WS>(fr); });
-        }
-        a[0] = n[0];
-        a[1] = n[1];
-        a[2] = n[2];
-        if constexpr (t == NT - 1) B = Bn;
-        // a step's side work stays in its step (mlp_x6.h, cvt_pk_bf16: the asm conversions must keep their distance from the MFMAs
-        // that read their results, which are those of the NEXT k-step)
-        __builtin_amdgcn_sched_barrier(0);
-    });
-    // hand over retired fragments (those of the next layer's first step, when this layer ends inside a slice)
-    if constexpr (!LAST && (F0 + kX6KFrags * NP) % kX6SliceFrags != 0) retire3<0>(a);
-    pref[0] = a[0];
-    pref[1] = a[1];
-    pref[2] = a[2];
-}
-// the stores of a layer's last slice that are younger than the pieces of the slice the NEXT layer opens first (that layer
-// must start on a slice boundary): the layer's last kSliceSteps - kFirstYoungStep steps
-template <class ST, int NT, int KS>
-constexpr int tail_younger() {
-    return ST::in_steps(NT * KS - (kX6SliceFrags / kX6KFrags - kFirstYoungStep), NT * KS - 1, NT * KS);
-}
-
 // a hidden layer (kernel body, `hidden`): k-steps S0 .. KS - 1 come from the input accumulators (prepared during k-steps
 // S0 - 1 .. KS - 2), and its last k-step prepares the next layer's first unless that one is an encoding k-step
 template <int NT, int KS, int S0, bool NEXT_PE, bool SAVE>
@@ -347,12 +244,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
                     }
                 }
             };
-            run_layer<F0, NT, KS, decltype(OYc)::value, HiddenStoresT<NT, KS, S0, NEXT_PE, SAVE>>(Out, B, side, ws, fr, pref, hook);
+            run_layer<F0, NT, KS, (F0 + kX6KFrags * NT * KS == kX6UsedFrags), decltype(OYc)::value, HiddenStoresT<NT, KS, S0, NEXT_PE, SAVE>>(Out, B, side, ws, fr, pref, hook);
         };
 
         // ---- biases of pts_linears.0, pieces of its first k-step
         static_for<8>([&](auto T_) { bias_tile(X[decltype(T_)::value], bias_h + bias_off(0) + 32 * decltype(T_)::value); });
         pe_kstep(ic<0>{}, B);
+        settle(B);   // (the other encoding pieces are first read k-steps later)
         const auto no_tail = [](KP&) {};
         // row stores still in flight when a layer opens its first slice = the young stores of the layer before it
         constexpr int kY_L0 = tail_younger<HiddenStoresT<8, 4, 4, false, SAVE>, 8, 4>();        // pts_linears.0: only its last k-step prepares
@@ -391,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
                     prepare_half<NT, t, 0, 0, SAVE>(X[0], Bn, rout);
                 }
             };
-            run_layer<F0, NT, KS, kY_H, Views0Stores>(X, B, side, ws, fr, pref, NoHook{});
+            run_layer<F0, NT, KS, false, kY_H, Views0Stores>(X, B, side, ws, fr, pref, NoHook{});
         }
         const float sigma = X[4][0];   // channel 128 = tile 4, register 0, lane half 0
         // ---- views_linears.1, .2 : 128 -> 128
@@ -407,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
                     if constexpr (SAVE && sn == 7) mask_store(kActV1 + 2);
                 }
             };
-            run_layer<f0(11), 1, 8, 0, Stores<1, 1, 8, SAVE>>(Y, B, side, ws, fr, pref, NoHook{});
+            run_layer<f0(11), 1, 8, true, 0, Stores<1, 1, 8, SAVE>>(Y, B, side, ws, fr, pref, NoHook{});
         }
         finish_pass6<kX6UsedFrags, kX6StreamFrags>(ws);
 

@@ -559,6 +559,8 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
             });
         }
 
+        settle(in_rgb);   // (asm conversion results, read by the first stage's MFMAs right away: mlp_x6.h)
+        settle(in_sig);
         PTile6 Pt[8];
         f32x16 O[8];
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

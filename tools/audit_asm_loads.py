@@ -152,23 +152,37 @@ def audit_inflight(insts, labels, name):
 THREE_SLOT_RING = re.compile(r"mlp_bf16x6_kernelILi\dELb0E")   # the inference six-piece forward: pieces are fetched TWO slices ahead
 
 
-def audit_asm_valu_to_mfma(insts, name, window=8):
-    """Fourth check, straight-line: an MFMA reading (as A / B operand) a VGPR that an inline-asm vector instruction wrote fewer
-    than `window` instructions earlier.  The recogniser inserts no wait states for what it cannot see: a v_cvt_pk_bf16_f32
-    in asm followed two MFMAs later by the MFMA that read its result returned garbage (round 3)."""
-    bad, recent = 0, []
+def wait_states(code):
+    """Wait states an instruction puts between a vector write before it and an MFMA after it, as measured on MI355X
+    (tools/valu_mfma_hazard_ubench.hip, profiles/r03_valu_mfma_hazard.log): s_nop N gives N + 1; one vector or scalar ALU
+    instruction gives one (NOT enough on its own); an MFMA or an LDS / vector-memory instruction gives at least two."""
+    op = code.split()[0]
+    if op == 's_nop':
+        return int(code.split()[1], 0) + 1
+    if op.startswith(('v_mfma', 'ds_', 'buffer_', 'global_', 'flat_', 'scratch_')):
+        return 2
+    return 1
+
+
+def audit_asm_valu_to_mfma(insts, name):
+    """Fourth check, straight-line: an MFMA reading (as A / B operand) a VGPR that an inline-asm vector instruction wrote with
+    fewer than TWO wait states in between.  Measured: with none or one (`s_nop 0` -- which is what hipcc puts behind an asm
+    statement -- or one ALU instruction) the MFMA reads the OLD register value.  The hazard recogniser inserts the wait states
+    for instructions it can see, not for inline asm: a build whose asm v_cvt_pk_bf16_f32 was followed by `s_nop 0` and the
+    MFMA reading it returned garbage (round 3)."""
+    bad, recent = 0, []     # (registers, wait states since, line)
     for idx, (no, code, in_asm) in enumerate(insts):
-        recent = [(r, i, n0) for r, i, n0 in recent if idx - i < window]
         if code.startswith('v_mfma'):
             ops = code.split(None, 1)[1].split(',')
             srcs = regs(','.join(ops[1:3]))          # srcA, srcB
-            for r, i, n0 in recent:
-                if r & srcs:
+            for r, ws, n0 in recent:
+                if ws < 2 and r & srcs:
                     bad += 1
-                    print(f"  {name}: line {no}: `{code}` reads a register an inline-asm vector instruction wrote {idx - i} instructions earlier (line {n0})")
+                    print(f"  {name}: line {no}: `{code}` reads a register an inline-asm vector instruction wrote {ws} wait state(s) earlier (line {n0})")
                     break
-        elif in_asm and code.startswith('v_') and not code.startswith('v_mfma'):
-            recent.append((regs(code.split(None, 1)[1].split(',')[0]), idx, no))
+        recent = [(r, ws + wait_states(code), n0) for r, ws, n0 in recent if ws + wait_states(code) < 2]
+        if in_asm and code.startswith('v_') and not code.startswith('v_mfma'):
+            recent.append((regs(code.split(None, 1)[1].split(',')[0]), 0, no))
     return bad
 
 
