@@ -29,7 +29,10 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6   # dense bf16 MFMA: 16x the fp32 rate (1024 FLOP
 # training step, per ray-sample: forward (as above) + dX (the transposed products of every layer that has a
 # hidden input: 7 x 256x256 + 256x129 + 2 x 128x128 + 128x3 MAC) + dW (every forward product once more)
 FLOP_PER_SAMPLE_DX = 2 * (7 * 65536 + 256 * 129 + 2 * 16384 + 384)     # 1 049 856
-FLOP_PER_SAMPLE_DW_X6 = 7 * 2 * 256 * 256     # dW of pts_linears.1..7 (the 256-wide part of .5): 917 504 of the 1 114 368
+# dW products that run on the bf16 pipe (six piece products each): pts_linears.1..7 (the 256-wide part of .5), views_linears.0's
+# 128 units + alpha_linear against a8 (one 256 x 256 launch), views_linears.1 / .2 (the diagonal blocks of one 256 x 256 launch):
+# 1 049 088 of the 1 114 368; the rest (pts_linears.0, pts_linears.5's encoding columns, rgb_linear) stays on the fp32 MFMA kernel
+FLOP_PER_SAMPLE_DW_X6 = 2 * (7 * 256 * 256 + 256 + 256 * 128 + 2 * 128 * 128)
 FLOP_PER_SAMPLE_STEP = FLOP_PER_SAMPLE + FLOP_PER_SAMPLE_DX + FLOP_PER_SAMPLE   # 3 278 592 (SURVEY's 3x rounds up by 2 %)
 
 

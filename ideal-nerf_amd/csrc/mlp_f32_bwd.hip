@@ -82,8 +82,8 @@ struct DeltaArgs {
     long p_pad;
     const float* d_rgb;   // [p_pad, 64]
     float* dv0;           // [p_pad, 256]
-    float* dv2;           // [p_pad, 128]
-    float* dv1;           // [p_pad, 128]
+    float* dv2;           // columns 0..127 of a [p_pad, 256] matrix (row pitch 256): delta of views_linears.2
+    float* dv1;           // columns 128..255 of the same matrix: delta of views_linears.1
     float* da[8];
 };
 
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
         f32x16(&B4)[4] = reinterpret_cast<f32x16(&)[4]>(B);
 
         // 0: rgb_linear^T : d rgb (3) -> delta of views_linears.2, masked by its output v3
-        stage_run(ic<0>{}, ic<bwd_f0(0)>{}, ic<0>{}, ic<128>{}, A4,
+        stage_run(ic<0>{}, ic<bwd_f0(0)>{}, ic<0>{}, ic<256>{}, A4,
                   [&](auto G, auto J) {
                       constexpr int g = decltype(G)::value, j = decltype(J)::value;
                       if constexpr (g == 0 && j < 3) return h ? 0.0f : drgb[j];
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void delta_chain_kernel(DeltaArgs a) {
                   },
                   9, a.dv2);
         // 1: views_linears.2^T -> delta of views_linears.1 (mask v2);  2: views_linears.1^T -> views_linears.0 (mask v1)
-        stage_run(ic<1>{}, ic<bwd_f0(1)>{}, ic<0>{}, ic<128>{}, B4, tiles_get(A), 8, a.dv1);
+        stage_run(ic<1>{}, ic<bwd_f0(1)>{}, ic<0>{}, ic<256>{}, B4, tiles_get(A), 8, a.dv1);
         stage_run(ic<2>{}, ic<bwd_f0(2)>{}, ic<0>{}, ic<256>{}, A4, tiles_get(B), 7, a.dv0);
         // 3: views_linears.0[:, :256]^T + alpha_linear^T (d sigma as k-channel 128) -> delta of pts_linears.7 (mask a8)
         stage_run(ic<3>{}, ic<bwd_f0(3)>{}, ic<1>{}, ic<256>{}, B,
@@ -586,9 +586,9 @@ __global__ __launch_bounds__(256, 1) void delta_chain_x6_kernel(DeltaArgs a) {
             static_for<NT>([&](auto T) { convert_tile<false>(O[decltype(T)::value], Pt[decltype(T)::value]); });
         };
         // 0: rgb_linear^T : d rgb (3) -> delta of views_linears.2, masked by its output v3
-        stage_run(ic<bwd6_f0(0)>{}, ic<4>{}, ic<1>{}, ic<0>{}, ic<128>{}, ic<0>{}, [&](auto Q, auto) { return in_rgb[decltype(Q)::value]; }, 9, a.dv2);
+        stage_run(ic<bwd6_f0(0)>{}, ic<4>{}, ic<1>{}, ic<0>{}, ic<256>{}, ic<0>{}, [&](auto Q, auto) { return in_rgb[decltype(Q)::value]; }, 9, a.dv2);
         // 1: views_linears.2^T -> delta of views_linears.1 (mask v2);  2: views_linears.1^T -> views_linears.0 (mask v1)
-        stage_run(ic<bwd6_f0(1)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<128>{}, ic<0>{}, tiles, 8, a.dv1);
+        stage_run(ic<bwd6_f0(1)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<256>{}, ic<0>{}, tiles, 8, a.dv1);
         stage_run(ic<bwd6_f0(2)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<256>{}, ic<0>{}, tiles, 7, a.dv0);
         // 3: views_linears.0[:, :256]^T + alpha_linear^T (d sigma as k-channel 128) -> delta of pts_linears.7 (mask a8)
         stage_run(ic<bwd6_f0(3)>{}, ic<8>{}, ic<9>{}, ic<1>{}, ic<256>{}, ic<0>{},

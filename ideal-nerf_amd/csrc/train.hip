@@ -37,6 +37,12 @@ struct TNArgs {
     long P;                    // rows (multiple of 32)
     int chunks_per_split;      // kTnRows-row chunks per split
     float* cpart;              // optional [splits][N]: column sums of A (the bias gradient), from the k-block-0 workgroups
+    // gemm_tn_x6_kernel only: B as TWO 128-column matrices (row pitch ldb each), columns 0..127 at B + b_off0 bytes and
+    // columns 128..255 at B + b_off1 bytes -- two 128 x 128 products as the diagonal blocks of one 256 x 256 launch
+    int b_split, b_off0, b_off1;
+    // (skipping the MFMAs of the unwanted tiles -- the off-diagonal blocks of a paired launch, rows 129..255 of views_linears.0 +
+    //  alpha_linear -- behind wave-uniform branches was tried: the accumulators then flow through phis, hipcc copies registers whose
+    //  asm loads are in flight (556 sites in tools/audit_asm_loads.py, results no longer reproducible) and the kernel ran 1.6x slower)
 };
 
 // The two 32-row chunk tiles are double-buffered in LDS and filled by LDS-DMA (a chunk row is
@@ -398,19 +404,21 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNArgs g) {
     const tn_i32x4 rsrcA = make_rsrc(g.A + c_begin * kTnRows * (long)g.lda);
     const tn_i32x4 rsrcB = make_rsrc(g.B + c_begin * kTnRows * (long)g.ldb);
     const int voff = tid * 4;
+    const int voffB = g.b_split ? (tid < 128 ? g.b_off0 : g.b_off1) + (tid & 127) * 4 : voff;
     const int rowA = g.lda * 4, rowB = g.ldb * 4;
     float ra[kTnRows], rb[kTnRows];
 #pragma unroll
     for (int p = 0; p < kTnRows; ++p) ra[p] = rb[p] = 0.f;
-    auto load_row = [&](float& dst, const tn_i32x4& rsrc, int soff) {
-        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    auto load_row_at = [&](float& dst, const tn_i32x4& rsrc, int soff, int vo) {
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(soff) : "memory");
     };
+    auto load_row = [&](float& dst, const tn_i32x4& rsrc, int soff) { load_row_at(dst, rsrc, soff, voff); };
     auto load_chunk = [&](int rc) {   // chunk rc of this split, clamped to its last one (re-read, never used)
         const int base = (rc < n_chunks ? rc : n_chunks - 1) * kTnRows;
 #pragma unroll
         for (int p = 0; p < kTnRows; ++p) load_row(ra[p], rsrcA, (base + p) * rowA);
 #pragma unroll
-        for (int p = 0; p < kTnRows; ++p) load_row(rb[p], rsrcB, (base + p) * rowB);
+        for (int p = 0; p < kTnRows; ++p) load_row_at(rb[p], rsrcB, (base + p) * rowB, voffB);
     };
     // this thread's slot: tile tid / 32, lane (tid % 32, hh) -> hh-th half of the fragment
     char* const my_slot = x6_smem + (tid >> 5) * (3 * kFragBytes) + (tid & 31) * 16;
@@ -523,8 +531,8 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNArgs g) {
                     t1 = t1 - __uint_as_float(p2 & 0xffff0000u);
                     pw[X][2][j] = tn_cvt_pk_bf16(t0, t1);
                 } else {
-                    load_row(r[2 * j], X ? rsrcB : rsrcA, (nbase + 2 * j) * (X ? rowB : rowA));
-                    load_row(r[2 * j + 1], X ? rsrcB : rsrcA, (nbase + 2 * j + 1) * (X ? rowB : rowA));
+                    load_row_at(r[2 * j], X ? rsrcB : rsrcA, (nbase + 2 * j) * (X ? rowB : rowA), X ? voffB : voff);
+                    load_row_at(r[2 * j + 1], X ? rsrcB : rsrcA, (nbase + 2 * j + 1) * (X ? rowB : rowA), X ? voffB : voff);
                     if constexpr (j >= 3 && j < 6) store(ic_<j - 3>{}, ic_<0>{});
                     if constexpr (j == 7) store(ic_<0>{}, ic_<1>{});
                 }
@@ -793,8 +801,9 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kMaxSplits = 256;
 constexpr int kColsumBlocks = 256;   // rows of the column-sum partial buffer (>= kMaxSplits)
 constexpr int kGemmsPerPass = 16;
-// partial-slab floats of one split over all GEMMs of a pass: 8 of 256x256, 3 of 256x64, 2 of 128x128, 1 of 64x128
-constexpr size_t kPartFloatsPerSplit = 8 * 65536 + 3 * 16384 + 2 * 16384 + 8192;
+// partial-slab floats of one split over all GEMMs of a pass: 9 of 256x256 (pts_linears.1..7, views_linears.0 + alpha_linear, the
+// views_linears.1 / .2 pair), 2 of 256x64, 1 of 128x64, 1 of 64x128 -- with room for the fp32 pipe's two 128x128
+constexpr size_t kPartFloatsPerSplit = 9 * 65536 + 4 * 16384 + 2 * 8192;   // (the fp32 pipe: 8 + 2 x 16384 for the views pair)
 
 struct BwdWs {
     float *dA[8], *dV[2], *dV0, *dRGB, *part, *cpart, *wbwd;
@@ -809,8 +818,10 @@ static BwdWs carve_bwd(char* base, int64_t p_pad) {
         return p;
     };
     for (int l = 0; l < 8; ++l) w.dA[l] = take((size_t)p_pad * 256);  // delta of pts_linears.l (pre-activation)
-    w.dV[0] = take((size_t)p_pad * 128);
-    w.dV[1] = take((size_t)p_pad * 128);
+    // delta of views_linears.2 | delta of views_linears.1 side by side in ONE 256-column matrix: their two 128 x 128 weight
+    // gradients are then the diagonal blocks of a single 256 x 256 product (launch_pass_bwd)
+    w.dV[0] = take((size_t)p_pad * 256);
+    w.dV[1] = w.dV[0] + 128;
     w.dV0 = take((size_t)p_pad * 256);
     w.dRGB = take((size_t)p_pad * 64);
     w.part = take((size_t)kMaxSplits * kPartFloatsPerSplit);   // one slab per GEMM of the pass: they are all reduced at its end
@@ -839,8 +850,10 @@ static int env_pipe_f32() {
 }
 static int default_gemm_pipe() { return (IDN_DW_X6 && !env_pipe_f32()) ? kPipeX6 : kPipeF32; }
 static int run_tn_partials(const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part,
-                           int* splits_out, hipStream_t s, float* cpart = nullptr, int pipe = -1) {
+                           int* splits_out, hipStream_t s, float* cpart = nullptr, int pipe = -1, const float* B2 = nullptr) {
     if (pipe < 0) pipe = default_gemm_pipe();
+    // B2: the x6 kernel's split-B form (two 128-column matrices, B for output columns 0..127 and B2 for 128..255)
+    if (B2 && !(N == 256 && K == 256 && pipe == kPipeX6)) return fail(IDN_EINVAL, "gemm_tn: a split B needs the 256 x 256 bf16-piece kernel");
     int ntw, ktw;
     if (N == 256 && K == 256) { ntw = 4; ktw = 4; }
     else if (N == 256 && K == 64) { ntw = 4; ktw = 1; }
@@ -856,7 +869,16 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
     if (splits < 1) splits = 1;
     const int cps = (int)((chunks + splits - 1) / splits);
     splits = (int)((chunks + cps - 1) / cps);
-    TNArgs g{A, lda, B, ldb, part, N, K, (long)P, cps, cpart};
+    TNArgs g{A, lda, B, ldb, part, N, K, (long)P, cps, cpart, 0, 0, 0};
+    if (B2) {   // byte offsets from the lower of the two addresses (buffer offsets are unsigned)
+        const float* base = B < B2 ? B : B2;
+        const int64_t o0 = (int64_t)(B - base) * 4, o1 = (int64_t)(B2 - base) * 4;
+        if (o0 >= (int64_t)1 << 31 || o1 >= (int64_t)1 << 31) return fail(IDN_EUNSUPPORTED, "gemm_tn: split B matrices more than 2 GiB apart");
+        g.B = base;
+        g.b_split = 1;
+        g.b_off0 = (int)o0;
+        g.b_off1 = (int)o1;
+    }
     const dim3 grid(bx, by, splits), block(256);
     const size_t lds = (size_t)kTnBufs * kTnRows * (size_t)(64 * ntw + 64 * ktw) * 4;
     static LaunchSetup setup;
@@ -983,10 +1005,10 @@ struct ReduceQueue {
 };
 // GEMM into a fresh slab of the pool; *part_out / *cpart_out are where its partial blocks went
 static int run_tn_q(ReduceQueue& q, const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, int* splits,
-                    const float** part_out, const float** cpart_out, bool colsum, hipStream_t s, int pipe) {
+                    const float** part_out, const float** cpart_out, bool colsum, hipStream_t s, int pipe, const float* B2 = nullptr) {
     float* part = q.part_next;
     float* cpart = colsum ? q.cpart_next : nullptr;
-    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, splits, s, cpart, pipe)) return e;
+    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, splits, s, cpart, pipe, B2)) return e;
     q.part_next += (size_t)(*splits) * N * K;
     if (colsum) q.cpart_next += (size_t)(*splits) * N;
     *part_out = part;
@@ -1066,22 +1088,37 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
     // weight and bias gradients: dW_l = delta_l^T a_{l-1} (contraction over the points), db_l = column sums
     ReduceQueue q(w.part, w.cpart);
     TRY(run_tn(q, w.dRGB, 64, 64, v_l(3), 128, 128, Pp, gr.rgb_w, 128, 3, 128, s, gr.rgb_b, 3));
-    TRY(run_tn(q, w.dV[0], 128, 128, v_l(2), 128, 128, Pp, gr.views_w[2], 128, 128, 128, s, gr.views_b[2], 128));
-    TRY(run_tn(q, w.dV[1], 128, 128, v_l(1), 128, 128, Pp, gr.views_w[1], 128, 128, 128, s, gr.views_b[1], 128));
-    // views_linears.0: its 128 units against [a8 | dirPE] (the expr columns are folded); alpha_linear, whose delta is the
-    // single column d sigma (dV0[:, 128]), as a weighted column sum of a8
-    TRY(run_tn(q, w.dV0, 256, 128, a_l(8), 256, 256, Pp, gr.views_w[0], ldv, 128, 256, s, gr.views_b[0], 128));
-    TRY(run_tn(q, w.dV0, 256, 128, act(kActDir), 64, 64, Pp, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH, s));
-    {
-        float* part = q.part_next;
-        float* partw = q.cpart_next;
-        q.part_next += (size_t)kWsumBlocks * 256;
-        q.cpart_next += kWsumBlocks;
-        hipLaunchKernelGGL(wsum_kernel, dim3(kWsumBlocks), dim3(256), 0, s, w.dV0 + kSigmaChannel, 256, a_l(8), 256, (long)Pp, part, partw);
-        IDN_HIP_CHECK(hipGetLastError());
-        TRY(q.add(part, kWsumBlocks, 1, 256, 0, 0, gr.alpha_w, 256, 1, 256));
-        TRY(q.add(partw, kWsumBlocks, 1, 1, 0, 0, gr.alpha_b, 1, 1, 1));
+    // views_linears.2 and .1 (128 x 128 each): on the bf16 pipe ONE 256 x 256 launch whose A is the side-by-side delta matrix and
+    // whose B columns come from the two activation matrices (v2 | v1) -- the weight gradients are its diagonal blocks, and 1 KB per
+    // point and layer is read once by a kernel that runs at the HBM rate (two fp32-MFMA launches took 1.7x as long).  The
+    // off-diagonal blocks are computed and dropped.
+    const int pipe = default_gemm_pipe();
+    if (pipe == kPipeX6) {
+        int splits = 0;
+        const float *part, *cpart;
+        TRY(run_tn_q(q, w.dV[0], 256, 256, v_l(2), 128, 256, Pp, &splits, &part, &cpart, true, s, pipe, v_l(1)));
+        TRY(q.add(cpart, splits, 1, 256, 0, 0, gr.views_b[2], 128, 1, 128));
+        TRY(q.add(cpart, splits, 1, 256, 0, 128, gr.views_b[1], 128, 1, 128));
+        TRY(q.add(part, splits, 256, 256, 0, 0, gr.views_w[2], 128, 128, 128));
+        TRY(q.add(part, splits, 256, 256, 128, 128, gr.views_w[1], 128, 128, 128));
+    } else {
+        TRY(run_tn(q, w.dV[0], 256, 128, v_l(2), 128, 128, Pp, gr.views_w[2], 128, 128, 128, s, gr.views_b[2], 128));
+        TRY(run_tn(q, w.dV[1], 256, 128, v_l(1), 128, 128, Pp, gr.views_w[1], 128, 128, 128, s, gr.views_b[1], 128));
     }
+    // views_linears.0 and alpha_linear against a8 in ONE 256 x 256 product: A = the 256-column matrix dV0, whose columns 0..127
+    // are views_linears.0's deltas and whose column 128 is d sigma (alpha_linear's delta); columns 129..255 are never written --
+    // whatever they hold only reaches output rows 129..255, which are not read.  (It replaces a 128 x 256 fp32-MFMA product and
+    // a weighted column sum that read dV0 and a8 once each.)  The direction-encoding columns stay a product of their own.
+    {
+        int splits = 0;
+        const float *part, *cpart;
+        TRY(run_tn_q(q, w.dV0, 256, 256, a_l(8), 256, 256, Pp, &splits, &part, &cpart, true, s, pipe));
+        TRY(q.add(cpart, splits, 1, 256, 0, 0, gr.views_b[0], 128, 1, 128));
+        TRY(q.add(cpart, splits, 1, 256, 0, kSigmaChannel, gr.alpha_b, 1, 1, 1));
+        TRY(q.add(part, splits, 256, 256, 0, 0, gr.views_w[0], ldv, 128, 256));
+        TRY(q.add(part, splits, 256, 256, kSigmaChannel, 0, gr.alpha_w, 256, 1, 256));
+    }
+    TRY(run_tn(q, w.dV0, 256, 128, act(kActDir), 64, 64, Pp, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH, s));
     for (int l = 7; l >= 1; --l) {
         const float* cur = w.dA[l];
         if (l == 5) {
