@@ -38,4 +38,4 @@ print("largest gaps (us): ")
 for g, a, b in gaps[:14]:
     print(f"  {g / 1e3:8.1f}  after {a.split('(')[0][:50]:50s} before {b.split('(')[0][:50]}")
 import statistics
-print("gap histogram (us):", {lim: sum(1 for g in gaps if g / 1e3 >= lim) for lim in (1, 3, 10, 30, 100)})
+print("gap histogram (us):", {lim: sum(1 for g, _, _ in gaps if g / 1e3 >= lim) for lim in (1, 3, 10, 30, 100)})
