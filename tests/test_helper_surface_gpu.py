@@ -251,7 +251,7 @@ def test_ops_reject_bad_shapes_devices_and_dtypes(idn, dev):
         ops.query_points_fwd(None, None, torch.zeros((4, 8, 3), device=dev), torch.zeros((5, 3), device=dev))
     dims = oracle.facenerf_dims()
     net = idn.FaceNeRF(dim_aud=64, dim_latent=32, dim_expr=76).to(dev)
-    packed = net.packed_weights()
+    packed = net.packed_weights("f32")     # (the ops default to the fp32 kernel whatever the modules' default arithmetic is)
     folded = net.folded_bias(*[torch.zeros(k, device=dev) for k in (64, 76, 32)])
     with pytest.raises(E, match="packed"):
         ops.query_rays_fwd(packed[:-4].contiguous(), folded, rays, z)
@@ -408,7 +408,8 @@ def test_obama_configs_render_by_name(idn, dev, cfg_name):
     flat = {k: v.reshape((-1,) + tuple(v.shape[2:])) for k, v in ref.items()}
     # fixed 1e-4 behind the sampling, exact sampling stage, coarse weights within 1e-5: every ray (tests/parity_proof.py)
     prove_render(idn, cfg_name.split("/")[-2] + " band", tapped, flat, net.face_nerf_fine.packed_weights(), ff, rays, bc,
-                 lambda z: oracle_fine_pass(pf, dims, rays, bc, syn["aud"], syn["expr"] if cfg.dim_expr else None, syn["latent"], z), 2e-4)
+                 lambda z: oracle_fine_pass(pf, dims, rays, bc, syn["aud"], syn["expr"] if cfg.dim_expr else None, syn["latent"], z), 2e-4,
+                 precision_fine=net.face_nerf_fine.prec_code)
     fl, _ = flipped_rows(tapped["tap_inds"], flat["tap_inds"])
     keep = torch.from_numpy(~fl)
     # last_weight is bounded by 1 and may be ~1e-17: absolute error, on the rays whose sample positions are the oracle's
