@@ -917,69 +917,6 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
     *splits_out = splits;
     return IDN_OK;
 }
-// part[b][k] = sum over block b's rows of w[row] * B[row][k] (k < 256), partw[b] = sum of w[row]: the gradient of a
-// single output unit fed by B -- alpha_linear, whose delta (d sigma) is one column.  It used to ride as channel 128
-// of views_linears.0's 256-wide delta matrix, which made that layer's dW GEMMs 256 rows tall for 129 used.
-constexpr int kWsumBlocks = 1024;   // 4 per CU: the kernel is a latency-bound stream (1 KiB of B per row)
-__global__ __launch_bounds__(256) void wsum_kernel(const float* __restrict__ w, int wld, const float* __restrict__ B, int ldb,
-                                                   long P, float* __restrict__ part, float* __restrict__ partw) {
-    // wave v of the block takes rows r0 + v, r0 + v + 4, ...; lane l the four columns 4 l .. 4 l + 3 (one dwordx4 per row)
-    __shared__ f32x4 red[4][64];
-    __shared__ float redw[4];
-    const long rows = (P + gridDim.x - 1) / gridDim.x;
-    const long r0 = (long)blockIdx.x * rows;
-    long r1 = r0 + rows;
-    if (r1 > P) r1 = P;
-    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
-    f32x4 s[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float sw = 0.f;
-    long r = r0 + v;
-    for (; r + 12 < r1; r += 16) {   // four rows of this wave in flight
-        float wv[4];
-        f32x4 bv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            wv[u] = w[(r + 4 * u) * wld];
-            bv[u] = *reinterpret_cast<const f32x4*>(B + (r + 4 * u) * ldb + 4 * lane);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            s[u].x = fmaf(wv[u], bv[u].x, s[u].x);
-            s[u].y = fmaf(wv[u], bv[u].y, s[u].y);
-            s[u].z = fmaf(wv[u], bv[u].z, s[u].z);
-            s[u].w = fmaf(wv[u], bv[u].w, s[u].w);
-            sw += wv[u];
-        }
-    }
-    for (; r < r1; r += 4) {
-        const float w0 = w[r * wld];
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(B + r * ldb + 4 * lane);
-        s[0].x = fmaf(w0, b0.x, s[0].x);
-        s[0].y = fmaf(w0, b0.y, s[0].y);
-        s[0].z = fmaf(w0, b0.z, s[0].z);
-        s[0].w = fmaf(w0, b0.w, s[0].w);
-        sw += w0;
-    }
-    f32x4 t;
-    t.x = (s[0].x + s[1].x) + (s[2].x + s[3].x);
-    t.y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
-    t.z = (s[0].z + s[1].z) + (s[2].z + s[3].z);
-    t.w = (s[0].w + s[1].w) + (s[2].w + s[3].w);
-    red[v][lane] = t;
-    if (lane == 0) redw[v] = sw;
-    __syncthreads();
-    if (v == 0) {
-        const f32x4 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
-        f32x4 o;
-        o.x = (a.x + b.x) + (c.x + d.x);
-        o.y = (a.y + b.y) + (c.y + d.y);
-        o.z = (a.z + b.z) + (c.z + d.z);
-        o.w = (a.w + b.w) + (c.w + d.w);
-        *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * 256 + 4 * lane) = o;
-        if (lane == 0) partw[blockIdx.x] = (redw[0] + redw[1]) + (redw[2] + redw[3]);
-    }
-}
-
 // The reductions of a pass are queued and launched together (flush) once every GEMM has been issued.
 struct ReduceQueue {
     ReduceBatch b;
