@@ -83,6 +83,11 @@ __device__ __forceinline__ void prepare_half(f32x16& acc, KP& out, const Recorde
 template <int NT, int KS, int S0, bool NEXT_PE, bool SAVE>
 using HiddenStoresT = Stores<NT, (S0 > 0 ? S0 : 1), (NEXT_PE ? KS : KS + 1), SAVE>;
 // views_linears.0: k-steps 1..15 from the trunk, 16 and 17 direction pieces, and its last k-step prepares views_linears.1's first
+template <class ST_, int NP_>
+struct PrevLayer {   // the layer in front of a layer: its row stores and its number of steps (run_layer's PST, PNP)
+    using ST = ST_;
+    static constexpr int NP = NP_;
+};
 template <bool SAVE>
 struct Views0StoresT {
     static constexpr int at(int s, int t) { return Stores<5, 1, 16, SAVE>::at(s, t) + Stores<5, 18, 19, SAVE>::at(s, t); }
@@ -97,7 +102,7 @@ template <int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
-    using WS = std::conditional_t<SAVE, WStream6, WStream6x3>;   // inference: three ring slots (pieces fetched two slices ahead)
+    using WS = WStream6x3;   // three ring slots: pieces fetched two slices ahead
     float* bias_s = reinterpret_cast<float*>(smem + WS::kSlotsT * kX6SliceFrags * kFragBytes);
 
     const int tid = threadIdx.x;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
         //   s + 1 == KS : the NEXT layer's first k-step -- half tile (0, 0) of Out (recorded under out_idx), unless that
         //                 layer starts with encoding pieces (next_pe) -- and that layer's biases into `In`.
         // ---------------------------------------------------------------------------------------------------------
-        auto hidden = [&](auto F0c, auto NTc, auto KSc, auto S0c, auto OYc, f32x16* In, f32x16* Out, int in_idx, int in_ld, int out_idx, int out_ld,
+        auto hidden = [&](auto F0c, auto NTc, auto KSc, auto S0c, auto Prev, f32x16* In, f32x16* Out, int in_idx, int in_ld, int out_idx, int out_ld,
                           auto NTnext, const float* bias_nxt, auto next_pe, auto&& tail_pieces, auto&& hook) __attribute__((always_inline)) {
             constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KS = decltype(KSc)::value, S0 = decltype(S0c)::value;
             constexpr bool NEXT_PE = decltype(next_pe)::value;
@@ -244,7 +249,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
                     }
                 }
             };
-            run_layer<F0, NT, KS, (F0 + kX6KFrags * NT * KS == kX6UsedFrags), decltype(OYc)::value, HiddenStoresT<NT, KS, S0, NEXT_PE, SAVE>>(Out, B, side, ws, fr, pref, hook);
+            using P = decltype(Prev);
+            run_layer<F0, NT, KS, (F0 + kX6KFrags * NT * KS == kX6UsedFrags), typename P::ST, P::NP, HiddenStoresT<NT, KS, S0, NEXT_PE, SAVE>>(Out, B, side, ws, fr, pref, hook);
         };
 
         // ---- biases of pts_linears.0, pieces of its first k-step
@@ -252,26 +258,29 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
         pe_kstep(ic<0>{}, B);
         settle(B);   // (the other encoding pieces are first read k-steps later)
         const auto no_tail = [](KP&) {};
-        // row stores still in flight when a layer opens its first slice = the young stores of the layer before it
-        constexpr int kY_L0 = tail_younger<HiddenStoresT<8, 4, 4, false, SAVE>, 8, 4>();        // pts_linears.0: only its last k-step prepares
-        constexpr int kY_H = tail_younger<HiddenStoresT<8, 16, 0, false, SAVE>, 8, 16>();       // a 256 x 256 layer
-        constexpr int kY_L4 = tail_younger<HiddenStoresT<8, 16, 0, true, SAVE>, 8, 16>();       // pts_linears.4: its last k-step hands over encoding pieces
-        constexpr int kY_L5 = tail_younger<HiddenStoresT<8, 20, 4, false, SAVE>, 8, 20>();
+        // the layer before each layer (its row stores and its number of steps): what may still be in flight at a slice barrier
+        using PrevNone = PrevLayer<NoStores, 1>;                                           // (the pass before: nothing counted)
+        using PrevL0 = PrevLayer<HiddenStoresT<8, 4, 4, false, SAVE>, 8 * 4>;              // pts_linears.0: only its last k-step prepares
+        using PrevH = PrevLayer<HiddenStoresT<8, 16, 0, false, SAVE>, 8 * 16>;             // a 256 x 256 layer
+        using PrevL4 = PrevLayer<HiddenStoresT<8, 16, 0, true, SAVE>, 8 * 16>;             // pts_linears.4: its last k-step hands over encoding pieces
+        using PrevL5 = PrevLayer<HiddenStoresT<8, 20, 4, false, SAVE>, 8 * 20>;
+        using PrevV0 = PrevLayer<Views0Stores, 5 * 18>;
+        using PrevV = PrevLayer<HiddenStoresT<4, 8, 0, false, SAVE>, 4 * 8>;
         // ---- pts_linears.0 : PE(64) -> 256 (into X).  Its k-steps are encoding pieces; its last one prepares (X[0], half 0).
-        hidden(ic<f0(0)>{}, ic<8>{}, ic<4>{}, ic<4>{}, ic<0>{}, Y, X, kActA1, 256, kActA1 + 0, 256, ic<8>{}, bias_h + bias_off(1), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(0)>{}, ic<8>{}, ic<4>{}, ic<4>{}, PrevNone{}, Y, X, kActA1, 256, kActA1 + 0, 256, ic<8>{}, bias_h + bias_off(1), ic<0>{}, no_tail, NoHook{});
         // ---- pts_linears.1..4
-        hidden(ic<f0(1)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_L0>{}, X, Y, kActA1 + 0, 256, kActA1 + 1, 256, ic<8>{}, bias_h + bias_off(2), ic<0>{}, no_tail, NoHook{});
-        hidden(ic<f0(2)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_H>{}, Y, X, kActA1 + 1, 256, kActA1 + 2, 256, ic<8>{}, bias_h + bias_off(3), ic<0>{}, no_tail, NoHook{});
-        hidden(ic<f0(3)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_H>{}, X, Y, kActA1 + 2, 256, kActA1 + 3, 256, ic<8>{}, bias_h + bias_off(4), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(1)>{}, ic<8>{}, ic<16>{}, ic<0>{}, PrevL0{}, X, Y, kActA1 + 0, 256, kActA1 + 1, 256, ic<8>{}, bias_h + bias_off(2), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(2)>{}, ic<8>{}, ic<16>{}, ic<0>{}, PrevH{}, Y, X, kActA1 + 1, 256, kActA1 + 2, 256, ic<8>{}, bias_h + bias_off(3), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(3)>{}, ic<8>{}, ic<16>{}, ic<0>{}, PrevH{}, X, Y, kActA1 + 2, 256, kActA1 + 3, 256, ic<8>{}, bias_h + bias_off(4), ic<0>{}, no_tail, NoHook{});
         // pts_linears.4's output (a5) is not the first thing pts_linears.5 reads: its first four k-steps are the encoding
-        hidden(ic<f0(4)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_H>{}, Y, X, kActA1 + 3, 256, kActA1 + 4, 256, ic<8>{}, bias_h + bias_off(5), ic<1>{},
+        hidden(ic<f0(4)>{}, ic<8>{}, ic<16>{}, ic<0>{}, PrevH{}, Y, X, kActA1 + 3, 256, kActA1 + 4, 256, ic<8>{}, bias_h + bias_off(5), ic<1>{},
                [&](KP& Bn) { pe_kstep(ic<0>{}, Bn); }, NoHook{});
         // ---- pts_linears.5 : [PE(64) | 256] -> 256 (X -> Y)
-        hidden(ic<f0(5)>{}, ic<8>{}, ic<20>{}, ic<4>{}, ic<kY_L4>{}, X, Y, kActA1 + 4, 256, kActA1 + 5, 256, ic<8>{}, bias_h + bias_off(6), ic<0>{}, no_tail,
+        hidden(ic<f0(5)>{}, ic<8>{}, ic<20>{}, ic<4>{}, PrevL4{}, X, Y, kActA1 + 4, 256, kActA1 + 5, 256, ic<8>{}, bias_h + bias_off(6), ic<0>{}, no_tail,
                [&]() { load_point<MODE>(a, tile + gridDim.x, wave, m, nxt); });
         // ---- pts_linears.6, .7
-        hidden(ic<f0(6)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_L5>{}, Y, X, kActA1 + 5, 256, kActA1 + 6, 256, ic<8>{}, bias_h + bias_off(7), ic<0>{}, no_tail, [&]() { touch_point(nxt); });
-        hidden(ic<f0(7)>{}, ic<8>{}, ic<16>{}, ic<0>{}, ic<kY_H>{}, X, Y, kActA1 + 6, 256, kActA1 + 7, 256, ic<5>{}, bias_h + bias_off(8), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(6)>{}, ic<8>{}, ic<16>{}, ic<0>{}, PrevL5{}, Y, X, kActA1 + 5, 256, kActA1 + 6, 256, ic<8>{}, bias_h + bias_off(7), ic<0>{}, no_tail, [&]() { touch_point(nxt); });
+        hidden(ic<f0(7)>{}, ic<8>{}, ic<16>{}, ic<0>{}, PrevH{}, X, Y, kActA1 + 6, 256, kActA1 + 7, 256, ic<5>{}, bias_h + bias_off(8), ic<0>{}, no_tail, NoHook{});
         // ---- views_linears.0 (+ alpha_linear as channel 128): [256 | dirPE(32)] -> 160 (Y -> X[0..4]).
         //      Tiles 0..3 are hidden units; tile 4 is not: its row 0 is sigma.  k-steps 16, 17 are direction pieces.
         {
@@ -289,12 +298,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
                     prepare_half<NT, t, 0, 0, SAVE>(X[0], Bn, rout);
                 }
             };
-            run_layer<F0, NT, KS, false, kY_H, Views0Stores>(X, B, side, ws, fr, pref, NoHook{});
+            run_layer<F0, NT, KS, false, typename PrevH::ST, PrevH::NP, Views0Stores>(X, B, side, ws, fr, pref, NoHook{});
         }
         const float sigma = X[4][0];   // channel 128 = tile 4, register 0, lane half 0
         // ---- views_linears.1, .2 : 128 -> 128
-        hidden(ic<f0(9)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<0>{}, X, Y, kActV1, 128, kActV1 + 1, 128, ic<4>{}, bias_h + bias_off(10), ic<0>{}, no_tail, NoHook{});
-        hidden(ic<f0(10)>{}, ic<4>{}, ic<8>{}, ic<0>{}, ic<0>{}, Y, X, kActV1 + 1, 128, kActV1 + 2, 128, ic<1>{}, bias_h + bias_off(11), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(9)>{}, ic<4>{}, ic<8>{}, ic<0>{}, PrevV0{}, X, Y, kActV1, 128, kActV1 + 1, 128, ic<4>{}, bias_h + bias_off(10), ic<0>{}, no_tail, NoHook{});
+        hidden(ic<f0(10)>{}, ic<4>{}, ic<8>{}, ic<0>{}, PrevV{}, Y, X, kActV1 + 1, 128, kActV1 + 2, 128, ic<1>{}, bias_h + bias_off(11), ic<0>{}, no_tail, NoHook{});
         // ---- rgb_linear : 128 -> 3 (rows 0..2 of one tile, Y[0]); its k-steps record v3
         {
             const Recorder rin{mk, act_row(kActV1 + 2, 128)};
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x6_kernel(MlpArgs a) {
                     if constexpr (SAVE && sn == 7) mask_store(kActV1 + 2);
                 }
             };
-            run_layer<f0(11), 1, 8, true, 0, Stores<1, 1, 8, SAVE>>(Y, B, side, ws, fr, pref, NoHook{});
+            run_layer<f0(11), 1, 8, true, typename PrevV::ST, PrevV::NP, Stores<1, 1, 8, SAVE>>(Y, B, side, ws, fr, pref, NoHook{});
         }
         finish_pass6<kX6UsedFrags, kX6StreamFrags>(ws);
 
@@ -347,7 +356,7 @@ int launch_mlp_bf16x6(const float* packed, const float* folded, const float* x, 
     if (acts && (x || pts)) return fail(IDN_EUNSUPPORTED, "the activation-saving forward takes rays");
     static LaunchSetup setup;
     int num_cu = 0;
-    constexpr int kLdsInfer = x6::mlp_lds6<x6::WStream6x3>(), kLdsTrain = x6::mlp_lds6<x6::WStream6>();
+    constexpr int kLdsInfer = x6::mlp_lds6<x6::WStream6x3>(), kLdsTrain = kLdsInfer;
     static_assert(kLdsInfer <= 160 * 1024, "LDS per CU");
     if (int e = setup.get([]() -> int {
             IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&x6::mlp_bf16x6_kernel<kModeRays, false>),

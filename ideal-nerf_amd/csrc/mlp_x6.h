@@ -72,8 +72,9 @@ __device__ __forceinline__ void convert_tile(const f32x16& acc, PTile6& out) {
 }
 
 // The six-piece streams: 48-fragment ring slots (16 k-steps of three fragments), 12 LDS-DMA pieces per wave and slice.
-// Two slots (96 KiB) everywhere but in the inference forward, which has the LDS for three (144 KiB): its pieces are then
-// fetched two slices ahead and have more than a slice and a half to land before the barrier that opens their slice.
+// The forward kernels have the LDS for three slots (144 KiB): pieces are fetched two slices ahead and have more than a slice
+// and a half to land before the barrier that opens their slice -- and so have the row stores of the training variant, which
+// retire in issue order with them.  The delta chain keeps two (96 KiB).
 using WStream6 = WStreamT<4, kX6SliceFrags>;
 using WStream6x3 = WStreamT<4, kX6SliceFrags, 3>;
 static_assert(WStream6::kPieces == 12 && kX6NumSlices % 3 == 0, "two pieces at each of the first six k-steps of a slice; slot phase static across passes");
@@ -146,22 +147,35 @@ struct Stores {
         return n;
     }
 };
-constexpr int kFirstYoungStep = 5;   // in-slice step from which a wave's stores are younger than its pieces of the next slice
+constexpr int kFirstYoungStep = 5;   // in-slice step from which a wave's stores are younger than the pieces it issued in that slice
+struct NoStores {   // the layer before stores nothing (or nothing is known about it: counting fewer stores than were issued is always safe)
+    static constexpr int at(int, int) { return 0; }
+    static constexpr int in_steps(int, int, int) { return 0; }
+};
+// The row stores a wave may leave in flight at the barrier that follows step `pi` (-1: the barrier in front of the layer's
+// first step) of a layer with NP steps and stores ST, behind a layer with PNP steps and stores PST.  The barrier opens the
+// slice whose pieces were issued in steps 0..5 of the slice AHEAD slices back (two-slot ring: the slice that ends here;
+// three-slot ring: the one before it), so every store since step kFirstYoungStep of THAT slice is younger than those
+// pieces.  Stores further back than the layer before are not counted (a stricter wait, never a weaker one).
+template <class ST, int NP, class PST, int PNP, int AHEAD>
+constexpr int young_stores(int pi) {
+    constexpr int kSliceSteps = kX6SliceFrags / kX6KFrags;
+    const int first = pi - (AHEAD * kSliceSteps - 1) + kFirstYoungStep;   // first step of the window [first, pi]
+    return ST::in_steps(first, pi, NP) + (first < 0 ? PST::in_steps(PNP + first, PNP - 1, PNP) : 0);
+}
 
 // One layer (forward) or stage (delta chain), K-major.  LAST: nothing is read ahead past its last step (the end of the
 // stream, or padding that is walked, not read).  On entry O[0..NT) hold the layer's biases (the stage's zeros), B the pieces of its k-step 0, `pref` the fragments
 // of its first step (unless the layer starts on a slice boundary).  side(ic<s>, ic<t>, Bn) runs inside step (s, t) and
 // fills Bn, the pieces of the NEXT k-step (of this layer, or -- in the layer's last k-step -- of the next layer, along
-// with that layer's biases).  ST: the row stores the side work issues (training), see Stores.
-template <int F0, int NT, int KS, bool LAST, int OPEN_YOUNGER, class ST, class Side, class Hook, class WS>
+// with that layer's biases).  ST: the row stores the side work issues (training), see Stores; PST, PNP: those of the layer
+// before and its number of steps.
+template <int F0, int NT, int KS, bool LAST, class PST, int PNP, class ST, class Side, class Hook, class WS>
 __device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WS& ws, FragReader& fr, f32x4 (&pref)[3], Hook&& after_open) {
-    static_assert(WS::kSlotsT == 2 || (OPEN_YOUNGER == 0 && ST::in_steps(0, NT * KS - 1, NT * KS) == 0),
-                  "the deeper ring's counted waits are written for a kernel that stores nothing (inference)");
     constexpr int NP = NT * KS;
-    constexpr int kSliceSteps = kX6SliceFrags / kX6KFrags;
     static_assert(F0 % kX6KFrags == 0, "triples");
     if constexpr (F0 % kX6SliceFrags == 0) {
-        ws.template open_slice<OPEN_YOUNGER>();   // (training: the row stores of the layer before stay in flight)
+        ws.template open_slice<young_stores<ST, NP, PST, PNP, WS::kAheadT>(-1)>();   // (training: the young row stores of the layer before stay in flight)
         after_open();
         static_for<3>([&](auto Q) { pref[decltype(Q)::value] = issue6<F0 + decltype(Q)::value, WS>(fr); });
         retire3<0>(pref);
@@ -194,9 +208,7 @@ __device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WS& ws,
         O[t] = mfma_bf(a[0], B.p[2], O[t]);   // w1 a3
         O[t] = mfma_bf(a[2], B.p[0], O[t]);   // w3 a1
         if constexpr (next_crosses && pi + 1 < NP) {
-            // the slice that ends with this step: its steps from kFirstYoungStep on (those of them that belong to this layer)
-            constexpr int y = ST::in_steps(pi - (kSliceSteps - 1) + kFirstYoungStep, pi, NP);
-            ws.template open_slice<y>();
+            ws.template open_slice<young_stores<ST, NP, PST, PNP, WS::kAheadT>(pi)>();
             static_for<3>([&](auto Q) { n[decltype(Q)::value] = issue6<f + kX6KFrags + decltype(Q)::value, WS>(fr); });
         }
         a[0] = n[0];
@@ -213,13 +225,6 @@ __device__ __forceinline__ void run_layer(f32x16* O, KP& B, Side&& side, WS& ws,
     pref[1] = a[1];
     pref[2] = a[2];
 }
-// the stores of a layer's last slice that are younger than the pieces of the slice the NEXT layer opens first (that layer
-// must start on a slice boundary): the layer's last kSliceSteps - kFirstYoungStep steps
-template <class ST, int NT, int KS>
-constexpr int tail_younger() {
-    return ST::in_steps(NT * KS - (kX6SliceFrags / kX6KFrags - kFirstYoungStep), NT * KS - 1, NT * KS);
-}
-
 
 }  // namespace x6
 }  // namespace idn

@@ -149,7 +149,7 @@ def audit_inflight(insts, labels, name):
     return bad
 
 
-THREE_SLOT_RING = re.compile(r"mlp_bf16x6_kernelILi\dELb0E")   # the inference six-piece forward: pieces are fetched TWO slices ahead
+THREE_SLOT_RING = re.compile(r"mlp_bf16x6_kernelILi\dELb[01]E")   # the six-piece forwards (inference and training): pieces are fetched TWO slices ahead
 
 
 def wait_states(code):

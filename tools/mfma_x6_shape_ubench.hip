@@ -27,13 +27,14 @@ __global__ __launch_bounds__(256, 1) void k(const float* init, float* out, int i
     for (int g = 0; g < 2; ++g) for (int q = 0; q < 3; ++q) b[g][q] = *reinterpret_cast<const f32x4*>(init + 1024 * (1 + 3 * g + q) + lane * 4);
     float side[4] = {init[lane], init[lane + 1], init[lane + 2], init[lane + 3]};
     const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds + lane * 16;
-    f32x4 a[3], an[3];
-    for (int q = 0; q < 3; ++q) a[q] = b[0][q];
+    f32x4 fa[2][3];   // two fragment sets, ping-pong: step u multiplies set u & 1 while set (u + 1) & 1 is being read
+    for (int q = 0; q < 3; ++q) fa[0][q] = b[0][q];
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {   // two k-steps of eight tile-steps
-            constexpr int dummy = 0; (void)dummy;
             const int t = u & 7;
+            f32x4 (&a)[3] = fa[u & 1];
+            f32x4 (&an)[3] = fa[(u + 1) & 1];
 #pragma unroll
             for (int q = 0; q < 3; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(an[q]) : "v"(addr), "n"(0) : "memory");
             asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])::"memory");
@@ -54,7 +55,6 @@ __global__ __launch_bounds__(256, 1) void k(const float* init, float* out, int i
 #undef T12
             }
             __builtin_amdgcn_sched_barrier(0);
-            a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
             if (t == 7) {   // a new k-step: new pieces (a cheap permutation of the old ones keeps the data random)
                 for (int g = 0; g < 2; ++g) { f32x4 tmp = b[g][0]; b[g][0] = b[g][1]; b[g][1] = b[g][2]; b[g][2] = tmp; }
             }
