@@ -43,7 +43,7 @@ class RenderArgs(C.Structure):
                                   "tap_z_coarse", "tap_raw_coarse", "tap_weights_coarse", "tap_cdf", "tap_inds",
                                   "tap_z_samples", "tap_z_fine", "tap_raw_fine", "tap_weights_fine")] + \
                [("workspace", fp), ("workspace_bytes", C.c_size_t), ("precision_fine_plus1", C.c_int),
-                ("lindisp", C.c_int), ("white_bkgd", C.c_int), ("noise_coarse", fp), ("noise_fine", fp)]
+                ("lindisp", C.c_int), ("white_bkgd", C.c_int), ("noise_coarse", fp), ("noise_fine", fp), ("fused_march", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/idealnerf.h one to one

@@ -365,6 +365,11 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
     const size_t need = idealnerf_render_workspace_bytes(n, S, Ni);
     if (!a->workspace || a->workspace_bytes < need)
         return fail(IDN_EWORKSPACE, "workspace %zu bytes < required %zu", a->workspace_bytes, need);
+    if (a->fused_march) {
+        if (a->precision != IDN_PREC_F32 || prec_fine != IDN_PREC_F32) return fail(IDN_EUNSUPPORTED, "fused march: built for the fp32 arithmetic");
+        if (S != 64 || Ni != 128) return fail(IDN_EUNSUPPORTED, "fused march: built for n_samples = 64, n_importance = 128 (got %d, %d)", S, Ni);
+        if (a->noise_coarse || a->noise_fine) return fail(IDN_EUNSUPPORTED, "fused march: no density noise");
+    }
     hipStream_t st = (hipStream_t)stream_;
     const RenderWs w = carve(reinterpret_cast<char*>(a->workspace), n, S, Ni);
 
@@ -380,7 +385,8 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
         const float* rays = a->rays + r0 * IDN_RAY_FLOATS;
         const float* bc = a->bc_rgb + r0 * 3;
         if (int e = launch_coarse_depths(rays, a->t_vals, off(a->t_rand, r0 * S), c, S, a->lindisp, w.z_c, st)) return e;
-        if (int e = launch_mlp(a->precision, a->packed_coarse, a->folded_coarse, nullptr, rays, w.z_c, nullptr, nullptr, c * S, S, w.raw_c, st)) return e;
+        if (!a->fused_march)
+            if (int e = launch_mlp(a->precision, a->packed_coarse, a->folded_coarse, nullptr, rays, w.z_c, nullptr, nullptr, c * S, S, w.raw_c, st)) return e;
         idn_composite_out co = {};
         const bool fine = Ni > 0;
         co.rgb_map = off(fine ? a->rgb0 : a->rgb_map, r0 * 3);
@@ -391,6 +397,23 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
         co.rgb_fg = off(fine ? a->rgb_fg0 : a->rgb_fg, r0 * 3);
         co.last_weight = off(fine ? a->last_weight0 : a->last_weight, r0);
         if (int e = tap(off(a->tap_z_coarse, r0 * S), w.z_c, (size_t)c * S * 4)) return e;
+        if (a->fused_march) {   // one kernel from the coarse depths to the pixels; raw, weights, cdf and the fine depths stay in LDS
+            idn_composite_out fo = {};
+            fo.rgb_map = off(a->rgb_map, r0 * 3);
+            fo.disp_map = off(a->disp_map, r0);
+            fo.acc_map = off(a->acc_map, r0);
+            fo.depth_map = off(a->depth_map, r0);
+            fo.weights = off(a->tap_weights_fine, r0 * Sf);
+            fo.rgb_fg = off(a->rgb_fg, r0 * 3);
+            fo.last_weight = off(a->last_weight, r0);
+            const float* u = a->u_per_ray ? a->u + r0 * Ni : a->u;
+            if (int e = launch_render_fused(a->packed_coarse, a->folded_coarse, a->packed_fine, a->folded_fine, rays, bc, w.z_c, u, a->u_per_ray, c,
+                                            a->white_bkgd, co, fo, off(a->z_std, r0), off(a->tap_raw_coarse, r0 * S * 4), off(a->tap_raw_fine, r0 * Sf * 4),
+                                            off(a->tap_z_fine, r0 * Sf), off(a->tap_inds, r0 * Ni), off(a->tap_z_samples, r0 * Ni),
+                                            off(a->tap_cdf, r0 * (S - 1)), st))
+                return e;
+            continue;
+        }
         if (int e = tap(off(a->tap_raw_coarse, r0 * S * 4), w.raw_c, (size_t)c * S * 16)) return e;
         if (!fine) {
             if (int e = launch_composite(w.raw_c, w.z_c, rays, bc, c, S, off(a->noise_coarse, r0 * S), a->white_bkgd, co, st)) return e;

@@ -70,7 +70,9 @@ struct Diag {};
 // ---------------------------------------------------------------------------
 constexpr int kAhead = kRingSlots - 1;  // slices in flight ahead of the consumer
 
-template <int NW, int SLICE_FRAGS = kSliceFrags, int SLOTS = kRingSlots>
+// DUAL: the stream alternates between TWO packed networks pass by pass (the fused ray kernel: passes [0, dual_first) of
+// every dual_period passes read stream 0, the others stream 1); the descriptor is switched where the prefetch wraps.
+template <int NW, int SLICE_FRAGS = kSliceFrags, int SLOTS = kRingSlots, bool DUAL = false>
 struct WStreamT {
     static constexpr int kSliceFragsT = SLICE_FRAGS;               // fragments per ring slot (64; the six-piece streams: 48)
     static constexpr int kSliceBytesT = SLICE_FRAGS * kFragBytes;
@@ -88,6 +90,8 @@ struct WStreamT {
     int next_slice;
     int num_slices;     // slices in this stream (kNumSlices, or kPlainNumSlices for the plain-bf16 stream)
     char* ring_wave;    // ring + this wave's block of a slice (wave-uniform LDS destination base)
+    const float* dual_stream[2];          // DUAL only
+    int dual_first, dual_period, dual_pass;   // DUAL only: the pass whose slices are being FETCHED
 
     __device__ __forceinline__ void init(const float* stream, int slices, char* ring, int tid, int wave) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, slices * kSliceBytesT, 0x00020000);  // raw, untyped
@@ -107,7 +111,20 @@ struct WStreamT {
         if (++next_slice == num_slices) {
             next_slice = 0;
             soff = 0;
+            if constexpr (DUAL) {
+                if (++dual_pass == dual_period) dual_pass = 0;
+                rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dual_stream[dual_pass < dual_first ? 0 : 1]), 0, num_slices * kSliceBytesT, 0x00020000);
+            }
         }
+    }
+    __device__ __forceinline__ void init_dual(const float* stream0, const float* stream1, int first, int period, int slices, char* ring, int tid, int wave) {
+        static_assert(DUAL, "two streams");
+        dual_stream[0] = stream0;
+        dual_stream[1] = stream1;
+        dual_first = first;
+        dual_period = period;
+        dual_pass = 0;
+        init(stream0, slices, ring, tid, wave);
     }
     template <int SLOT, int J>
     __device__ __forceinline__ void issue_piece() {

@@ -1,0 +1,320 @@
+// The whole per-ray path of Network.render_rays (NeRFs/HeadNeRF/train/audio_exp_nerf.py:300-371) as ONE kernel, fp32:
+// coarse network on 64 samples -> raw2outputs -> sample_pdf -> merge -> fine network on 192 samples -> raw2outputs,
+// with the sample positions, the raw network outputs, the compositing weights and the cdf of a ray staged in LDS.
+// Nothing per-sample crosses HBM: a ray costs its 44-byte record, 256 bytes of coarse depths, 12 bytes of background
+// pixel in, and its output pixels out (north_star's "fused ray-march kernel").
+//
+// A persistent workgroup (one per CU, 4 waves) takes the rays in GROUPS of four:
+//   passes 0, 1   the coarse FaceNeRF on the group's 4 x 64 = 256 points (two 128-point tiles of the fp32 MLP kernel's
+//                 pass -- fused PE + 12 layers of v_mfma_f32_32x32x2_f32, weights streamed through the LDS ring; raw -> LDS)
+//   march         wave w composites ray w, inverts its cdf and merges the depths (march.h: the same device functions as
+//                 march_kernel, on LDS rows) -> 192 fine depths of ray w in LDS
+//   passes 2..7   the fine FaceNeRF on the group's 4 x 192 = 768 points (depths from LDS; raw -> LDS)
+//   composite     wave w composites ray w's 192 fine samples -> the output pixel
+// The weight ring alternates between the two packed networks (WStreamT<..., DUAL>: the descriptor is switched where the
+// prefetch wraps, so the first slice of the next pass's network is in flight during the last slice of this pass), and the
+// folded bias block in LDS is reloaded at the two network changes of a group.
+//
+// Same arithmetic as the three-kernel path (mlp_f32_kernel -> march_kernel -> mlp_f32_kernel -> composite_kernel), bit
+// for bit: tests/test_hip_parity.py::test_fused_ray_kernel_equals_the_unfused_path.  It is NOT the default
+// ("ns1"): with one wave per SIMD nothing hides the latency of the march, during which the matrix
+// pipe idles, and the 40 bytes per sample it keeps out of HBM were 0.2 % of the frame time.
+#include "march.h"
+#include "mlp_f32_layers.h"
+
+namespace idn {
+
+constexpr int kFG = 4;                              // rays per group (one per wave in the march)
+constexpr int kFS = 64, kFNi = 128, kFSf = kFS + kFNi;
+constexpr int kFCoarsePasses = kFG * kFS / 128;     // 2
+constexpr int kFFinePasses = kFG * kFSf / 128;      // 6
+constexpr int kFPasses = kFCoarsePasses + kFFinePasses;
+constexpr int kFScratchFloats = 64 + 64 + kFSf + 72;   // per wave: cdf, bins, val (pdf terms, then the merge), weights
+// LDS: ring | bias block | fine depths [4][192] | union { raw fine [768] x 16 B ; raw coarse [256] x 16 B + march scratch }
+constexpr int kFUnionBytes = kFG * kFSf * 16;
+static_assert(kFG * kFS * 16 + 4 * kFScratchFloats * 4 <= kFUnionBytes, "march scratch aliases the fine raw rows");
+constexpr int kFusedLds = kMlpLds + kFG * kFSf * 4 + kFUnionBytes;
+static_assert(kFusedLds <= 160 * 1024, "LDS per CU");
+
+struct FusedArgs {
+    const float* wstream_c;
+    const float* bias_c;
+    const float* wstream_f;
+    const float* bias_f;
+    const float* rays;   // [n, 11]
+    const float* bc;     // [n, 3]
+    const float* z_c;    // [n, 64] coarse depths (coarse_depths_kernel)
+    const float* u;
+    int u_per_ray;
+    long n_rays;
+    int white_bkgd;
+    idn_composite_out co, fo;   // outputs of the coarse / fine compositing, indexed by ray
+    float* z_std;
+    float* tap_raw_c;    // debug taps (any may be null)
+    float* tap_raw_f;
+    float* tap_z_fine;
+    int64_t* tap_inds;
+    float* tap_z_samples;
+    float* tap_cdf;
+};
+
+using WStreamDual = WStreamT<4, kSliceFrags, kRingSlots, true>;
+
+__global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    float* bias_s = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes);
+    float* zf_s = bias_s + kBiasFloats;
+    char* uni = reinterpret_cast<char*>(zf_s + kFG * kFSf);
+    float4* rawf_s = reinterpret_cast<float4*>(uni);
+    float4* rawc_s = reinterpret_cast<float4*>(uni);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    float* scratch = reinterpret_cast<float*>(uni + kFG * kFS * 16) + wave * kFScratchFloats;
+
+    Diag dg;
+    WStreamDual ws;
+    ws.dg = &dg;
+    ws.init_dual(a.wstream_c, a.wstream_f, kFCoarsePasses, kFPasses, kNumSlices, ring, tid, wave);
+    PeLane pln;
+    pln.init(h);
+    FragReader fr;
+    fr.addr0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
+    fr.addr1 = fr.addr0 + 64 * kFragBytes;
+    const float* bias_h = bias_s + 4 * h;
+    const long ngroups = (a.n_rays + kFG - 1) / kFG;
+
+    // this lane's point in pass p of a group: index q among the group's coarse (p < 2) or fine points
+    auto point_q = [&](int p) { return (p < kFCoarsePasses ? p : p - kFCoarsePasses) * 128 + wave * 32 + m; };
+    // ray record (and, in a coarse pass, the depth) of this lane's point in pass p of group g, clamped to the last ray
+    auto load_in = [&](long g, int p, PointIn& in) {
+        const int q = point_q(p);
+        const bool fine = p >= kFCoarsePasses;
+        const int rl = fine ? q / kFSf : q >> 6;
+        long ray = g * kFG + rl;
+        if (ray >= a.n_rays) ray = a.n_rays - 1;
+        const float* rr = a.rays + ray * IDN_RAY_FLOATS;
+        in.f[0] = rr[0]; in.f[1] = rr[1]; in.f[2] = rr[2];
+        in.f[3] = rr[3]; in.f[4] = rr[4]; in.f[5] = rr[5];
+        in.f[6] = rr[8]; in.f[7] = rr[9]; in.f[8] = rr[10];
+        in.f[9] = fine ? 0.0f : a.z_c[ray * kFS + (q & 63)];   // (fine depths come from LDS when the pass starts)
+    };
+
+    PointIn cur, nxt;
+    load_in(blockIdx.x, 0, cur);
+    nxt = cur;
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+#pragma unroll 1
+        for (int pass = 0; pass < kFPasses; ++pass) {
+            // (the pass number as an opaque scalar: left visible, hipcc peels and specialises the loop on it -- four copies of
+            //  the 1 680-MFMA pass body and 21 spilled registers)
+            int p = pass;
+            asm volatile("" : "+s"(p));
+            const bool fine = p >= kFCoarsePasses;
+            if (p == 0 || p == kFCoarsePasses) {   // a network change: its folded bias block (the last readers of the old one were the colour heads of the pass before)
+                __syncthreads();
+                const float* src = fine ? a.bias_f : a.bias_c;
+                for (int i = tid; i < kBiasFloats; i += 256) bias_s[i] = src[i];
+                __syncthreads();
+            }
+            const int q = point_q(p);
+            if (fine) cur.f[9] = zf_s[q];   // row q / 192, sample q % 192: the rows are contiguous
+
+            // ---- inputs: this lane's half of the 64 point features and 32 direction features
+            float pe[8][4], pd[4][4];
+            {
+                float pt[3], v[3];
+                point_of<kModeRays>(cur, pt, v);
+                PeAxes axp, axd;
+                axp.init(pt, h);
+                axd.init(v, h);
+                static_for<8>([&](auto G) {
+                    static_for<4>([&](auto J) {
+                        constexpr int gg = decltype(G)::value, j = decltype(J)::value;
+                        pe[gg][j] = pe_slot<8 * gg + j, 10>(axp, pln);
+                        if constexpr (gg < 4) pd[gg][j] = pe_slot<8 * gg + j, 4>(axd, pln);
+                    });
+                });
+            }
+
+            // ---- the pass: the inference path of mlp_f32_kernel (mlp_f32.hip), layer for layer
+            f32x16 A[8], B[8], V[5];
+            auto pe_get = [&](auto G, auto J) { return pe[decltype(G)::value][decltype(J)::value]; };
+            auto tiles_get = [](f32x16* arr) {
+                return [arr](auto G, auto J) {
+                    constexpr int gg = decltype(G)::value, j = decltype(J)::value;
+                    return arr[gg >> 2][(gg & 3) * 4 + j];
+                };
+            };
+            auto layer = [&](auto F0c, auto NTc, auto KGc, auto DEFERc, auto& out, f32x16* deferred, auto&& bget, const float* bias_l) {
+                constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KG = decltype(KGc)::value;
+                constexpr bool LAST = (F0 + NT * KG == kUsedFrags) || F0 == layer_f0(8) || F0 == layer_f0(10);
+                constexpr bool DEFER = decltype(DEFERc)::value != 0;
+                // the next pass's ray record: loaded after pts_linears.5's first slice opens, touched one layer later
+                auto hook = [&]() {
+                    if constexpr (F0 == layer_f0(5)) {
+                        const bool wraps = p + 1 == kFPasses;
+                        long gn = wraps ? g + gridDim.x : g;
+                        if (gn >= ngroups) gn = g;   // no next group: a valid, unused address
+                        load_in(gn, wraps ? 0 : p + 1, nxt);
+                    }
+                    if constexpr (F0 == layer_f0(6)) touch_point(nxt);
+                };
+                bias_tile(out[0], bias_l);
+                run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, LayerSide<NT, KG / 2, DEFER>{&out[0], deferred, bias_l}, hook);
+            };
+            layer(ic<layer_f0(0)>{}, ic<8>{}, ic<8>{}, ic<0>{}, A, nullptr, pe_get, bias_h + bias_off(0));
+#pragma unroll 1
+            for (int l = 1; l <= 3; l += 2) {
+                layer(ic<layer_f0(1)>{}, ic<8>{}, ic<32>{}, ic<1>{}, B, &A[7], tiles_get(A), bias_h + l * 256);
+                layer(ic<layer_f0(2)>{}, ic<8>{}, ic<32>{}, ic<1>{}, A, &B[7], tiles_get(B), bias_h + (l + 1) * 256);
+            }
+            layer(ic<layer_f0(5)>{}, ic<8>{}, ic<40>{}, ic<1>{}, B, &A[7],
+                  [&](auto G, auto J) {
+                      constexpr int gg = decltype(G)::value, j = decltype(J)::value;
+                      if constexpr (gg < 8) return pe[gg][j];
+                      else return A[(gg - 8) >> 2][((gg - 8) & 3) * 4 + j];
+                  },
+                  bias_h + bias_off(5));
+            layer(ic<layer_f0(6)>{}, ic<8>{}, ic<32>{}, ic<1>{}, A, &B[7], tiles_get(B), bias_h + bias_off(6));
+            layer(ic<layer_f0(7)>{}, ic<8>{}, ic<32>{}, ic<1>{}, B, &A[7], tiles_get(A), bias_h + bias_off(7));
+            f32x16(&V4a)[4] = reinterpret_cast<f32x16(&)[4]>(V);
+            layer(ic<layer_f0(8)>{}, ic<4>{}, ic<36>{}, ic<1>{}, V4a, &B[7],
+                  [&](auto G, auto J) {
+                      constexpr int gg = decltype(G)::value, j = decltype(J)::value;
+                      if constexpr (gg < 32) return B[gg >> 2][(gg & 3) * 4 + j];
+                      else return pd[gg - 32][j];
+                  },
+                  bias_h + bias_off(8));
+            relu_regs<0, 16>(V[3]);
+            {   // alpha_linear's tile of the stream is walked, not read (sigma is a dot product on the vector unit, below)
+                constexpr int f_from = layer_f0(8) + 4 * 36, f_to = layer_f0(9);
+                static_for<(f_to - f_from) / 2>([&](auto I) { ws.template step_piece<f_from + 2 * decltype(I)::value>(); });
+                fr.pref0 = fr.template issue<f_to>();
+                fr.pref1 = fr.template issue<f_to + 1>();
+            }
+            float sigma;
+            {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                static_for<8>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    static_for<4>([&](auto Q) {
+                        constexpr int qq = decltype(Q)::value;
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(bias_h + kAlphaOff + 32 * t + 8 * qq);
+                        s0 = fmaf(w.x, B[t][4 * qq + 0], s0);
+                        s1 = fmaf(w.y, B[t][4 * qq + 1], s1);
+                        s2 = fmaf(w.z, B[t][4 * qq + 2], s2);
+                        s3 = fmaf(w.w, B[t][4 * qq + 3], s3);
+                    });
+                });
+                const float part = (s0 + s1) + (s2 + s3);
+                sigma = bias_s[bias_off(8) + kSigmaChannel] + (part + __shfl_xor(part, 32, 64));
+            }
+            f32x16(&A4)[4] = reinterpret_cast<f32x16(&)[4]>(A);
+            f32x16(&V4b)[4] = reinterpret_cast<f32x16(&)[4]>(V);
+            layer(ic<layer_f0(9)>{}, ic<4>{}, ic<16>{}, ic<0>{}, A4, nullptr, tiles_get(V), bias_h + bias_off(9));
+            layer(ic<layer_f0(10)>{}, ic<4>{}, ic<16>{}, ic<1>{}, V4b, &A[3], tiles_get(A), bias_h + bias_off(10));
+            relu_regs<0, 16>(V[3]);
+            finish_pass<layer_f0(11)>(ws);
+            float rgb[3] = {bias_s[bias_off(11) + 0], bias_s[bias_off(11) + 1], bias_s[bias_off(11) + 2]};
+            {
+                float part[3] = {0.f, 0.f, 0.f};
+                static_for<4>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    f32x16 vt = V[t];
+                    asm volatile("" : "+v"(vt));
+                    static_for<3>([&](auto Cc) {
+                        constexpr int c = decltype(Cc)::value;
+                        static_for<4>([&](auto Q) {
+                            constexpr int qq = decltype(Q)::value;
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(bias_h + kRgbOff + 128 * c + 32 * t + 8 * qq);
+                            part[c] = fmaf(w.x, vt[4 * qq + 0], part[c]);
+                            part[c] = fmaf(w.y, vt[4 * qq + 1], part[c]);
+                            part[c] = fmaf(w.z, vt[4 * qq + 2], part[c]);
+                            part[c] = fmaf(w.w, vt[4 * qq + 3], part[c]);
+                        });
+                    });
+                    asm volatile("" : "+v"(part[0]), "+v"(part[1]), "+v"(part[2])::"memory");
+                });
+                static_for<3>([&](auto Cc) {
+                    constexpr int c = decltype(Cc)::value;
+                    rgb[c] += part[c] + __shfl_xor(part[c], 32, 64);
+                });
+            }
+
+            // ---- raw stays on chip (the optional taps copy it out)
+            if (h == 0) {
+                const float4 o = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+                (fine ? rawf_s : rawc_s)[q] = o;
+                float* tap = fine ? a.tap_raw_f : a.tap_raw_c;
+                const int per_ray = fine ? kFSf : kFS;
+                const long ray = g * kFG + q / per_ray;
+                if (tap && ray < a.n_rays) *reinterpret_cast<float4*>(tap + (ray * per_ray + q % per_ray) * 4) = o;
+            }
+            cur = nxt;
+
+            // ---- between the networks: wave w marches ray w of the group
+            if (p == kFCoarsePasses - 1) {
+                __syncthreads();
+                const long ray = g * kFG + wave;
+                float* zrow = zf_s + wave * kFSf;
+                if (ray < a.n_rays) {   // wave-uniform
+                    float* cdf = scratch;
+                    float* bins = scratch + 64;
+                    float* val = scratch + 128;
+                    float* wrow = scratch + 128 + kFSf;
+                    float wts[1];
+                    composite_ray<1>(rawc_s + wave * kFS, a.z_c + ray * kFS, a.rays, a.bc, ray, lane, kFS, nullptr, a.white_bkgd, a.co, wts);
+                    wrow[lane] = wts[0];
+                    wave_lds_fence();
+                    const SampleArgs sa{a.z_c, nullptr, nullptr, nullptr, a.u, a.u_per_ray, a.n_rays, kFS, kFNi, kFS - 1,
+                                        a.tap_z_samples, a.tap_inds, a.tap_cdf, a.tap_z_fine, a.z_std};
+                    sample_pdf_ray(sa, ray, lane, cdf, bins, val, wrow, zrow);
+                } else {
+                    for (int k = lane; k < kFSf; k += 64) zrow[k] = 0.0f;   // a padding ray: its points are computed and dropped
+                }
+                __syncthreads();
+            }
+            // ---- after the fine passes: wave w composites ray w
+            if (p == kFPasses - 1) {
+                __syncthreads();
+                const long ray = g * kFG + wave;
+                if (ray < a.n_rays) {
+                    float wts[3];
+                    composite_ray<3>(rawf_s + wave * kFSf, zf_s + wave * kFSf, a.rays, a.bc, ray, lane, kFSf, nullptr, a.white_bkgd, a.fo, wts);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // drain the slice prefetched for a pass that will not happen
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+}
+
+int launch_render_fused(const float* packed_c, const float* folded_c, const float* packed_f, const float* folded_f,
+                        const float* rays, const float* bc, const float* z_c, const float* u, int u_per_ray, int64_t n_rays,
+                        int white_bkgd, const idn_composite_out& co, const idn_composite_out& fo, float* z_std, float* tap_raw_c,
+                        float* tap_raw_f, float* tap_z_fine, int64_t* tap_inds, float* tap_z_samples, float* tap_cdf, hipStream_t s) {
+    if (n_rays <= 0) return IDN_OK;
+    static LaunchSetup setup;
+    int num_cu = 0;
+    if (int e = setup.get([]() -> int {
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));
+            return IDN_OK;
+        }, &num_cu))
+        return e;
+    const int64_t ngroups = (n_rays + kFG - 1) / kFG;
+    const int grid = (int)(ngroups < num_cu ? ngroups : num_cu);
+    FusedArgs a{packed_c, folded_c, packed_f, folded_f, rays, bc, z_c, u, u_per_ray, (long)n_rays, white_bkgd, co, fo, z_std,
+                tap_raw_c, tap_raw_f, tap_z_fine, tap_inds, tap_z_samples, tap_cdf};
+    ProfScope prof(s, n_rays * (kFS + kFSf), IDN_PROF_MLP_FWD);
+    hipLaunchKernelGGL(render_fused_kernel, dim3(grid), dim3(256), kFusedLds, s, a);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+}  // namespace idn

@@ -246,6 +246,12 @@ typedef struct idn_render_args {
     int white_bkgd;            /* rgb += 1 - acc, in both passes */
     const float* noise_coarse; /* [n, n_samples] or NULL: raw_noise_std noise of the coarse pass, drawn by the caller */
     const float* noise_fine;   /* [n, n_samples + n_importance] or NULL */
+    /* != 0: the whole per-ray path (both networks, the march between them and the final compositing) as ONE kernel that
+     * keeps a ray's sample positions, raw network outputs, weights and cdf in LDS -- nothing per-sample crosses HBM
+     * (csrc/render_fused.hip).  Same results as the default kernel sequence, bit for bit.  Built for the fp32 arithmetic
+     * at n_samples = 64, n_importance = 128 without density noise; anything else returns IDN_EUNSUPPORTED.  Off by
+     * default: it measures ~1-2 % slower than the kernel sequence. */
+    int fused_march;
 } idn_render_args;
 
 size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);

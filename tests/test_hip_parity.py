@@ -1475,6 +1475,38 @@ def test_render_unusual_sample_counts_vs_oracle(idn, dev, n_rays, S, Ni):
     assert abs_err(out["last_weight"][torch.from_numpy(~fl).to(dev)], ref["last_weight"][torch.from_numpy(~fl)]) < W_TOL
 
 
+@pytest.mark.parametrize("n_rays,jitter,with_fg", [(1, False, False), (6, False, True), (1031, False, False), (517, True, True)])
+def test_fused_ray_kernel_equals_the_unfused_path(idn, dev, n_rays, jitter, with_fg):
+    """north_star's fused ray-march kernel (csrc/render_fused.hip: both networks, the march between them and the final
+    compositing as ONE launch, a ray's depths / raw outputs / weights / cdf in LDS) against the default kernel sequence on
+    the same rays: every output and every tap BIT FOR BIT (it runs the same device functions on LDS rows), ragged ray
+    counts (groups of four rays, padding rays computed and dropped), per-ray u and stratified depths (perturb = 1), and the
+    torso variant's outputs.  The kernel sequence itself is pinned to the reference by the goldens above."""
+    dims, pc, pf, (pk_c, fold_c), (pk_f, fold_f) = _nets(idn, dev)
+    syn = oracle.synthetic_frame(48, 48, seed=7, dims=dims)
+    rays = idn.ops.frame_rays(syn["c2w"], 48, 48, syn["focal"], NEAR, FAR, device=dev)
+    sel = torch.from_numpy(np.random.RandomState(n_rays).choice(48 * 48, n_rays, replace=False))
+    r = rays[sel.to(dev)].contiguous()
+    bc = syn["bc"].reshape(-1, 3)[sel].contiguous().to(dev)
+    cond = (syn["aud"], syn["expr"], syn["latent"])
+    t = torch.linspace(0.0, 1.0, 64).to(dev)
+    g = torch.Generator().manual_seed(n_rays)
+    u = torch.rand((n_rays, 128), generator=g).to(dev) if jitter else torch.linspace(0.0, 1.0, 128).to(dev)
+    t_rand = torch.rand((n_rays, 64), generator=g).to(dev) if jitter else None
+    args = (r, bc, pk_c, fold_c(*cond), pk_f, fold_f(*cond), t, u, 128)
+    for taps in (True, False):
+        kw = dict(t_rand=t_rand, with_fg=with_fg, taps=taps)
+        seq = idn.ops.render_rays_fwd(*args, fused=False, **kw)
+        one = idn.ops.render_rays_fwd(*args, fused=True, **kw)
+        assert sorted(seq) == sorted(one)
+        for k in seq:
+            assert torch.isfinite(seq[k].float()).all(), k
+            assert torch.equal(seq[k], one[k]), f"{k}: fused != kernel sequence (max diff {(seq[k].double() - one[k].double()).abs().max().item():.3e})"
+    # what the fused kernel is not built for is refused, not approximated
+    with pytest.raises(idn._lib.IdealNerfError, match="fused march"):
+        idn.ops.render_rays_fwd(r, bc, pk_c, fold_c(*cond), pk_f, fold_f(*cond), torch.linspace(0.0, 1.0, 32).to(dev), u, 128, fused=True)
+
+
 def test_train_forward_defines_every_row_of_the_activation_slab(idn, dev):
     """The weight-gradient GEMMs contract over all p_pad rows of the saved activations, so the padding
     rows of a ragged pass must hold finite numbers (their deltas are zero, but 0 x NaN is not): fill

@@ -15,7 +15,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA
   rocprofv3 --pmc $set --output-format csv -d $O/pmc_$tag -- $B > $O/pmc_$tag.log 2>&1
   echo "pmc $tag done"
 done
-K=mlp_bf16x3_kernel; [ "$P" = "f32" ] && K=mlp_f32_kernel; [ "$P" = "bf16x6" ] && K=mlp_bf16x6_kernel; [ "$P" = "bf16" ] && K=mlp_bf16_kernel; [ "$P" = "fp16x3" ] && K=mlp_fp16x3_kernel
+K=mlp_bf16x3_kernel; [ "$P" = "f32" ] && K=${IDN_PROFILE_KERNEL:-mlp_f32_kernel}; [ "$P" = "bf16x6" ] && K=mlp_bf16x6_kernel; [ "$P" = "bf16" ] && K=mlp_bf16_kernel; [ "$P" = "fp16x3" ] && K=mlp_fp16x3_kernel
 python3 tools/pmc_summary.py $K $O/pmc_summary.json $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_WAVE_CYCLES $O/pmc_GRBM_GUI_ACTIVE > $O/pmc_summary.log
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 # raw counter dumps are large: keep only the summaries
