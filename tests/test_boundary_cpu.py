@@ -259,7 +259,7 @@ def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
         return str(out)
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
-        files = list(ex.map(compile_s, ["mlp_f32", "mlp_bf16x3", "mlp_bf16x6", "mlp_f32_bwd", "train"]))
+        files = list(ex.map(compile_s, ["mlp_f32", "mlp_bf16x3", "mlp_bf16x6", "render_fused", "mlp_f32_bwd", "train"]))
     for f in files:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), f, ""],
                            capture_output=True, text=True)

@@ -239,7 +239,7 @@ def audit(lines, name, full_name=None):
     bad = audit_inflight(insts, labels, name) + audit_mfma_to_asm_valu(insts, name) + audit_asm_valu_to_mfma(insts, name)
     # the two-slot weight ring of the MLP / delta-chain kernels: every barrier needs ALL of the wave's pieces.  (The dW GEMM's
     # three-buffer tiles leave the pieces of the NEXT chunk in flight on purpose: there the younger operations are pieces.)
-    if "mlp_" in name or "delta_chain" in name:
+    if "mlp_" in name or "delta_chain" in name or "render_fused" in name:
         bad += audit_counted_slice_waits(insts, labels, name, 3 if THREE_SLOT_RING.search(full_name or name) else 2)
     return bad
 

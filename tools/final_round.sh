@@ -13,6 +13,11 @@ timeout -k 10 900 python -m pytest tests -m gpu -q -s > $F/pytest_gpu_final.log 
 tail -1 $F/pytest_gpu_final.log
 IDN_DEFAULT_PRECISION=bf16x6 timeout -k 10 900 python -m pytest tests -m gpu -q > $F/pytest_gpu_bf16x6_as_default.log 2>&1 || true
 tail -1 $F/pytest_gpu_bf16x6_as_default.log
+# the fused ray kernel (the opt-in arrangement of the fp32 path) first: its summaries are taken from the same output directory
+IDN_FUSED_MARCH=1 IDN_PROFILE_KERNEL=render_fused_kernel bash tools/profile_round.sh f32 > $F/profile_render_fused.log 2>&1
+cp gpurun_out/prof_f32/pmc_summary.json $F/pmc_render_fused_final.json
+cp gpurun_out/prof_f32/kernel_stats.csv $F/kernel_stats_render_fused_final.csv
+echo "profile render_fused done"
 for P in f32 bf16x6; do
   bash tools/profile_round.sh $P > $F/profile_$P.log 2>&1
   cp gpurun_out/prof_$P/pmc_summary.json $F/pmc_mlp_${P}_final.json
@@ -28,6 +33,7 @@ if [ -f ideal-nerf_amd/libidealnerf_wrap.so ]; then bash tools/ab_bench.sh wrap 
 # the PMC summaries must be in profiles/ for bench.py to report `traffic`: stage them where it looks
 mkdir -p profiles
 for P in f32 bf16x6; do cp $F/pmc_mlp_${P}_final.json profiles/${ROUND:-r03}_pmc_mlp_${P}_final.json; done
+cp $F/pmc_render_fused_final.json profiles/${ROUND:-r03}_pmc_render_fused_final.json
 python bench.py > $F/bench_default.json 2> $F/bench_default.err
 python bench.py --precision bf16x6 --no-cpu-baseline > $F/bench_bf16x6.json 2>> $F/bench_default.err
 python bench.py --workload train --steps 12 --warmup 4 > $F/bench_train.json 2>> $F/bench_default.err
