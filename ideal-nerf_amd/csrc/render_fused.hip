@@ -140,110 +140,17 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
                 });
             }
 
-            // ---- the pass: the inference path of mlp_f32_kernel (mlp_f32.hip), layer for layer
-            f32x16 A[8], B[8], V[5];
-            auto pe_get = [&](auto G, auto J) { return pe[decltype(G)::value][decltype(J)::value]; };
-            auto tiles_get = [](f32x16* arr) {
-                return [arr](auto G, auto J) {
-                    constexpr int gg = decltype(G)::value, j = decltype(J)::value;
-                    return arr[gg >> 2][(gg & 3) * 4 + j];
-                };
-            };
-            auto layer = [&](auto F0c, auto NTc, auto KGc, auto DEFERc, auto& out, f32x16* deferred, auto&& bget, const float* bias_l) {
-                constexpr int F0 = decltype(F0c)::value, NT = decltype(NTc)::value, KG = decltype(KGc)::value;
-                constexpr bool LAST = (F0 + NT * KG == kUsedFrags) || F0 == layer_f0(8) || F0 == layer_f0(10);
-                constexpr bool DEFER = decltype(DEFERc)::value != 0;
-                // the next pass's ray record: loaded after pts_linears.5's first slice opens, touched one layer later
-                auto hook = [&]() {
-                    if constexpr (F0 == layer_f0(5)) {
-                        const bool wraps = p + 1 == kFPasses;
-                        long gn = wraps ? g + gridDim.x : g;
-                        if (gn >= ngroups) gn = g;   // no next group: a valid, unused address
-                        load_in(gn, wraps ? 0 : p + 1, nxt);
-                    }
-                    if constexpr (F0 == layer_f0(6)) touch_point(nxt);
-                };
-                bias_tile(out[0], bias_l);
-                run_layer<F0, NT, KG, LAST>(out, bget, ws, fr, LayerSide<NT, KG / 2, DEFER>{&out[0], deferred, bias_l}, hook);
-            };
-            layer(ic<layer_f0(0)>{}, ic<8>{}, ic<8>{}, ic<0>{}, A, nullptr, pe_get, bias_h + bias_off(0));
-#pragma unroll 1
-            for (int l = 1; l <= 3; l += 2) {
-                layer(ic<layer_f0(1)>{}, ic<8>{}, ic<32>{}, ic<1>{}, B, &A[7], tiles_get(A), bias_h + l * 256);
-                layer(ic<layer_f0(2)>{}, ic<8>{}, ic<32>{}, ic<1>{}, A, &B[7], tiles_get(B), bias_h + (l + 1) * 256);
-            }
-            layer(ic<layer_f0(5)>{}, ic<8>{}, ic<40>{}, ic<1>{}, B, &A[7],
-                  [&](auto G, auto J) {
-                      constexpr int gg = decltype(G)::value, j = decltype(J)::value;
-                      if constexpr (gg < 8) return pe[gg][j];
-                      else return A[(gg - 8) >> 2][((gg - 8) & 3) * 4 + j];
-                  },
-                  bias_h + bias_off(5));
-            layer(ic<layer_f0(6)>{}, ic<8>{}, ic<32>{}, ic<1>{}, A, &B[7], tiles_get(B), bias_h + bias_off(6));
-            layer(ic<layer_f0(7)>{}, ic<8>{}, ic<32>{}, ic<1>{}, B, &A[7], tiles_get(A), bias_h + bias_off(7));
-            f32x16(&V4a)[4] = reinterpret_cast<f32x16(&)[4]>(V);
-            layer(ic<layer_f0(8)>{}, ic<4>{}, ic<36>{}, ic<1>{}, V4a, &B[7],
-                  [&](auto G, auto J) {
-                      constexpr int gg = decltype(G)::value, j = decltype(J)::value;
-                      if constexpr (gg < 32) return B[gg >> 2][(gg & 3) * 4 + j];
-                      else return pd[gg - 32][j];
-                  },
-                  bias_h + bias_off(8));
-            relu_regs<0, 16>(V[3]);
-            {   // alpha_linear's tile of the stream is walked, not read (sigma is a dot product on the vector unit, below)
-                constexpr int f_from = layer_f0(8) + 4 * 36, f_to = layer_f0(9);
-                static_for<(f_to - f_from) / 2>([&](auto I) { ws.template step_piece<f_from + 2 * decltype(I)::value>(); });
-                fr.pref0 = fr.template issue<f_to>();
-                fr.pref1 = fr.template issue<f_to + 1>();
-            }
-            float sigma;
-            {
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                static_for<8>([&](auto T) {
-                    constexpr int t = decltype(T)::value;
-                    static_for<4>([&](auto Q) {
-                        constexpr int qq = decltype(Q)::value;
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(bias_h + kAlphaOff + 32 * t + 8 * qq);
-                        s0 = fmaf(w.x, B[t][4 * qq + 0], s0);
-                        s1 = fmaf(w.y, B[t][4 * qq + 1], s1);
-                        s2 = fmaf(w.z, B[t][4 * qq + 2], s2);
-                        s3 = fmaf(w.w, B[t][4 * qq + 3], s3);
-                    });
-                });
-                const float part = (s0 + s1) + (s2 + s3);
-                sigma = bias_s[bias_off(8) + kSigmaChannel] + (part + __shfl_xor(part, 32, 64));
-            }
-            f32x16(&A4)[4] = reinterpret_cast<f32x16(&)[4]>(A);
-            f32x16(&V4b)[4] = reinterpret_cast<f32x16(&)[4]>(V);
-            layer(ic<layer_f0(9)>{}, ic<4>{}, ic<16>{}, ic<0>{}, A4, nullptr, tiles_get(V), bias_h + bias_off(9));
-            layer(ic<layer_f0(10)>{}, ic<4>{}, ic<16>{}, ic<1>{}, V4b, &A[3], tiles_get(A), bias_h + bias_off(10));
-            relu_regs<0, 16>(V[3]);
-            finish_pass<layer_f0(11)>(ws);
-            float rgb[3] = {bias_s[bias_off(11) + 0], bias_s[bias_off(11) + 1], bias_s[bias_off(11) + 2]};
-            {
-                float part[3] = {0.f, 0.f, 0.f};
-                static_for<4>([&](auto T) {
-                    constexpr int t = decltype(T)::value;
-                    f32x16 vt = V[t];
-                    asm volatile("" : "+v"(vt));
-                    static_for<3>([&](auto Cc) {
-                        constexpr int c = decltype(Cc)::value;
-                        static_for<4>([&](auto Q) {
-                            constexpr int qq = decltype(Q)::value;
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(bias_h + kRgbOff + 128 * c + 32 * t + 8 * qq);
-                            part[c] = fmaf(w.x, vt[4 * qq + 0], part[c]);
-                            part[c] = fmaf(w.y, vt[4 * qq + 1], part[c]);
-                            part[c] = fmaf(w.z, vt[4 * qq + 2], part[c]);
-                            part[c] = fmaf(w.w, vt[4 * qq + 3], part[c]);
-                        });
-                    });
-                    asm volatile("" : "+v"(part[0]), "+v"(part[1]), "+v"(part[2])::"memory");
-                });
-                static_for<3>([&](auto Cc) {
-                    constexpr int c = decltype(Cc)::value;
-                    rgb[c] += part[c] + __shfl_xor(part[c], 32, 64);
-                });
-            }
+            // ---- the pass: mlp_f32_kernel's inference pass (mlp_f32_layers.h); the next pass's ray record is loaded after
+            //      pts_linears.5's first slice opens and touched one layer later
+            float rgb[3], sigma;
+            f32_inference_pass(pe, pd, bias_s, bias_h, ws, fr,
+                               [&]() {
+                                   const bool wraps = p + 1 == kFPasses;
+                                   long gn = wraps ? g + gridDim.x : g;
+                                   if (gn >= ngroups) gn = g;   // no next group: a valid, unused address
+                                   load_in(gn, wraps ? 0 : p + 1, nxt);
+                               },
+                               [&]() { touch_point(nxt); }, rgb, sigma);
 
             // ---- raw stays on chip (the optional taps copy it out)
             if (h == 0) {
