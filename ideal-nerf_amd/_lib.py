@@ -46,6 +46,8 @@ class RenderArgs(C.Structure):
                 ("lindisp", C.c_int), ("white_bkgd", C.c_int), ("noise_coarse", fp), ("noise_fine", fp), ("fused_march", C.c_int)]
 
 
+ABI_VERSION = 3   # idealnerf_version(): 3 since idn_render_args carries `fused_march`
+
 # name -> (restype, argtypes); mirrors include/idealnerf.h one to one
 PROTOTYPES = {
     "idealnerf_version": (C.c_int, []),
@@ -102,6 +104,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header and library out of sync
         fn.restype = res
         fn.argtypes = args
+    if lib.idealnerf_version() != ABI_VERSION:   # struct layouts above belong to one ABI version (IDN_LIB may point at an older build)
+        raise IdealNerfError(f"{LIB_PATH} has ABI version {lib.idealnerf_version()}, this package binds version {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

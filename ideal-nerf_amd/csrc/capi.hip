@@ -86,7 +86,7 @@ using namespace idn;
 
 extern "C" {
 
-int idealnerf_version(void) { return 2; }
+int idealnerf_version(void) { return 3; }   // 3: idn_render_args grew by `fused_march` (round 3)
 const char* idealnerf_last_error(void) { return g_err; }
 
 size_t idealnerf_packed_weight_floats(int precision) {

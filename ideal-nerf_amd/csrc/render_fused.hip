@@ -13,7 +13,7 @@
 //   composite     wave w composites ray w's 192 fine samples -> the output pixel
 // The weight ring alternates between the two packed networks (WStreamT<..., DUAL>: the descriptor is switched where the
 // prefetch wraps, so the first slice of the next pass's network is in flight during the last slice of this pass), and the
-// folded bias block in LDS is reloaded at the two network changes of a group.
+// folded bias block in LDS is exchanged at the two network changes of a group, its fetch hidden under the march / the compositing.
 //
 // Same arithmetic as the three-kernel path (mlp_f32_kernel -> march_kernel -> mlp_f32_kernel -> composite_kernel), bit
 // for bit: tests/test_hip_parity.py::test_fused_ray_kernel_equals_the_unfused_path.  It is NOT the default
@@ -30,10 +30,12 @@ constexpr int kFCoarsePasses = kFG * kFS / 128;     // 2
 constexpr int kFFinePasses = kFG * kFSf / 128;      // 6
 constexpr int kFPasses = kFCoarsePasses + kFFinePasses;
 constexpr int kFScratchFloats = 64 + 64 + kFSf + 72;   // per wave: cdf, bins, val (pdf terms, then the merge), weights
-// LDS: ring | bias block | fine depths [4][192] | union { raw fine [768] x 16 B ; raw coarse [256] x 16 B + march scratch }
+// LDS: ring | bias block (padded) | fine depths [4][192] | union { raw fine [768] x 16 B ; raw coarse [256] x 16 B + march scratch }
 constexpr int kFUnionBytes = kFG * kFSf * 16;
 static_assert(kFG * kFS * 16 + 4 * kFScratchFloats * 4 <= kFUnionBytes, "march scratch aliases the fine raw rows");
-constexpr int kFusedLds = kMlpLds + kFG * kFSf * 4 + kFUnionBytes;
+constexpr int kFBiasPerThread = (kBiasFloats + 255) / 256;       // 13: the block in LDS is padded to a whole number of floats per thread
+constexpr int kFBiasPadFloats = kFBiasPerThread * 256;
+constexpr int kFusedLds = kRingFrags * kFragBytes + kFBiasPadFloats * 4 + kFG * kFSf * 4 + kFUnionBytes;
 static_assert(kFusedLds <= 160 * 1024, "LDS per CU");
 
 struct FusedArgs {
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     float* bias_s = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes);
-    float* zf_s = bias_s + kBiasFloats;
+    float* zf_s = bias_s + kFBiasPadFloats;
     char* uni = reinterpret_cast<char*>(zf_s + kFG * kFSf);
     float4* rawf_s = reinterpret_cast<float4*>(uni);
     float4* rawc_s = reinterpret_cast<float4*>(uni);
@@ -103,6 +105,27 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
         in.f[9] = fine ? 0.0f : a.z_c[ray * kFS + (q & 63)];   // (fine depths come from LDS when the pass starts)
     };
 
+    // The folded bias block of the network in use sits in LDS (there is no room for both).  At a change of network the other
+    // one's 12.5 KB are fetched into registers BEFORE the march / the final compositing and written to LDS AFTER it, behind
+    // the barrier those need anyway: the fetch rides under work that does not touch the block (as a plain reload in front of
+    // the pass it cost two more barriers and an exposed round trip per change: 0.35 % of the frame).
+    // (buffer loads through a descriptor bounded to the block: one lane offset and compile-time steps instead of thirteen
+    //  64-bit addresses per lane, and the lanes past the end of the block read zeros into the LDS padding)
+    float bias_next[kFBiasPerThread];
+    const uint32_t bias_voff = tid * 4;
+    auto bias_fetch = [&](const float* src) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, kBiasFloats * 4, 0x00020000);
+        static_for<kFBiasPerThread>([&](auto I) {
+            bias_next[decltype(I)::value] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, bias_voff, 1024 * decltype(I)::value, 0));
+        });
+    };
+    auto bias_commit = [&]() {
+        static_for<kFBiasPerThread>([&](auto I) { bias_s[tid + 256 * decltype(I)::value] = bias_next[decltype(I)::value]; });
+    };
+    bias_fetch(a.bias_c);
+    bias_commit();
+    __syncthreads();
+
     PointIn cur, nxt;
     load_in(blockIdx.x, 0, cur);
     nxt = cur;
@@ -114,12 +137,6 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
             int p = pass;
             asm volatile("" : "+s"(p));
             const bool fine = p >= kFCoarsePasses;
-            if (p == 0 || p == kFCoarsePasses) {   // a network change: its folded bias block (the last readers of the old one were the colour heads of the pass before)
-                __syncthreads();
-                const float* src = fine ? a.bias_f : a.bias_c;
-                for (int i = tid; i < kBiasFloats; i += 256) bias_s[i] = src[i];
-                __syncthreads();
-            }
             const int q = point_q(p);
             if (fine) cur.f[9] = zf_s[q];   // row q / 192, sample q % 192: the rows are contiguous
 
@@ -165,7 +182,8 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
 
             // ---- between the networks: wave w marches ray w of the group
             if (p == kFCoarsePasses - 1) {
-                __syncthreads();
+                __syncthreads();   // (also: every wave is done with the coarse bias block)
+                bias_fetch(a.bias_f);
                 const long ray = g * kFG + wave;
                 float* zrow = zf_s + wave * kFSf;
                 if (ray < a.n_rays) {   // wave-uniform
@@ -183,16 +201,19 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
                 } else {
                     for (int k = lane; k < kFSf; k += 64) zrow[k] = 0.0f;   // a padding ray: its points are computed and dropped
                 }
+                bias_commit();
                 __syncthreads();
             }
             // ---- after the fine passes: wave w composites ray w
             if (p == kFPasses - 1) {
-                __syncthreads();
+                __syncthreads();   // (also: every wave is done with the fine bias block)
+                bias_fetch(a.bias_c);
                 const long ray = g * kFG + wave;
                 if (ray < a.n_rays) {
                     float wts[3];
                     composite_ray<3>(rawf_s + wave * kFSf, zf_s + wave * kFSf, a.rays, a.bc, ray, lane, kFSf, nullptr, a.white_bkgd, a.fo, wts);
                 }
+                bias_commit();
                 __syncthreads();
             }
         }

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(idn):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/idealnerf.h but not exported"
     assert sorted(idn._lib.PROTOTYPES) == names, "ctypes prototypes and header are out of sync"
-    assert lib.idealnerf_version() == 2
+    assert lib.idealnerf_version() == 3
     assert lib.idealnerf_folded_bias_floats() == 3136   # 2496 biases + alpha_linear (256) and rgb_linear (3 x 128) weight rows
     assert lib.idealnerf_packed_weight_floats(0) == 2304 * 256
     assert lib.idealnerf_packed_weight_floats(99) == 0

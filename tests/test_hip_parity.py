@@ -1495,7 +1495,8 @@ def test_fused_ray_kernel_equals_the_unfused_path(idn, dev, n_rays, jitter, with
     t_rand = torch.rand((n_rays, 64), generator=g).to(dev) if jitter else None
     args = (r, bc, pk_c, fold_c(*cond), pk_f, fold_f(*cond), t, u, 128)
     for taps in (True, False):
-        kw = dict(t_rand=t_rand, with_fg=with_fg, taps=taps)
+        # (the reference leaves white_bkgd and lindisp off; the one-kernel path takes them like the sequence does)
+        kw = dict(t_rand=t_rand, with_fg=with_fg, taps=taps, white_bkgd=not taps, lindisp=jitter and not taps)
         seq = idn.ops.render_rays_fwd(*args, fused=False, **kw)
         one = idn.ops.render_rays_fwd(*args, fused=True, **kw)
         assert sorted(seq) == sorted(one)
