@@ -377,7 +377,7 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
     same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it.  `fused=True`: the
     whole path as ONE kernel with a ray's samples, raw outputs and weights in LDS (csrc/render_fused.hip; fp32, 64 + 128
     samples, no density noise -- anything else raises); `fused=False`: the kernel sequence (network, march, network,
-    compositing).  Same results bit for bit, same speed to 0.2 %; the sequence moves less data (the fused kernel re-fetches
+    compositing).  Same results bit for bit, same speed to 0.1 % on a full frame; the sequence moves less data (the fused kernel re-fetches
     a network's 2.4 MB weight stream into every L2 at each change of network) and is the default.  `fused=None`: the
     kernel sequence, or the fused kernel wherever it applies when the process was started with IDN_FUSED_MARCH=1."""
     lib = _lib.load()
