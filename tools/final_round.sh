@@ -1,6 +1,6 @@
 #!/bin/bash
-# End-of-round measurements on ONE GPU box (one gpurun call; ~15 min): the GPU test log (also with bf16x6 as the module
-# default), the PMC / kernel-trace summaries of the fp32 and bf16x6 inference kernels and of the train step, the same-box
+# End-of-round measurements on ONE GPU box (one gpurun call; ~10 min): the GPU test log (also with bf16x6 as the module
+# default, and with the fused ray kernel as the default arrangement), the PMC / kernel-trace summaries of the fp32 and bf16x6 inference kernels and of the train step, the same-box
 # stream-wrap A/B of the shipped bf16x6 kernel, and the bench lines -- all into gpurun_out/final/, from where they are
 # copied to profiles/r<NN>_* by hand.
 #   ROUND=r03 IDN_COMMIT=$(git rev-parse --short HEAD) bash tools/final_round.sh        (the GPU box has no .git)
@@ -13,6 +13,8 @@ timeout -k 10 900 python -m pytest tests -m gpu -q -s > $F/pytest_gpu_final.log 
 tail -1 $F/pytest_gpu_final.log
 IDN_DEFAULT_PRECISION=bf16x6 timeout -k 10 900 python -m pytest tests -m gpu -q > $F/pytest_gpu_bf16x6_as_default.log 2>&1 || true
 tail -1 $F/pytest_gpu_bf16x6_as_default.log
+IDN_FUSED_MARCH=1 timeout -k 10 900 python -m pytest tests -m gpu -q > $F/pytest_gpu_fused_as_default.log 2>&1 || true
+tail -1 $F/pytest_gpu_fused_as_default.log
 # the fused ray kernel (the opt-in arrangement of the fp32 path) first: its summaries are taken from the same output directory
 IDN_FUSED_MARCH=1 IDN_PROFILE_KERNEL=render_fused_kernel bash tools/profile_round.sh f32 > $F/profile_render_fused.log 2>&1
 cp gpurun_out/prof_f32/pmc_summary.json $F/pmc_render_fused_final.json
