@@ -127,9 +127,20 @@ def cpu_model():
     return "unknown"
 
 
-KNAME_SEQ = "idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)"
-KNAME_FUSED = ("idn::render_fused_kernel (ONE launch per chunk: PE + coarse FaceNeRF, march, PE + fine FaceNeRF, compositing; fp32 MFMA; "
-               "a ray's depths, raw outputs, weights and cdf stay in LDS)")
+# the three arrangements of the fp32 64 + 128 per-ray path (idn_render_args::fused_march, IDN_FUSED_MARCH)
+KNAME = {0: "idn::mlp_f32_kernel<kModeRays> (fused PE + FaceNeRF MLP, fp32 MFMA)",
+         1: ("idn::render_fused_kernel<whole> (ONE launch per chunk: PE + coarse FaceNeRF, march, PE + fine FaceNeRF, compositing; fp32 MFMA; "
+             "a ray's depths, raw outputs, weights and cdf stay in LDS)"),
+         2: ("idn::render_fused_kernel<coarse> + <fine> (two launches per chunk: PE + coarse FaceNeRF + march | PE + fine FaceNeRF + "
+             "compositing; fp32 MFMA; raw outputs, weights and cdf stay in LDS, the fine depths cross HBM)")}
+ARRANGEMENT_BLOCK = {0: "kernel_sequence_mode", 1: "fused_march", 2: "fused_split"}
+ARRANGEMENT_PMC = {0: "mlp_f32", 1: "render_fused", 2: "render_split"}
+ARRANGEMENT_NOTE = ("the arrangements: (0) the kernel sequence mlp_f32_kernel -> march_kernel -> mlp_f32_kernel -> composite_kernel (raw network "
+                    "outputs and fine depths cross HBM: 40 B per sample, 0.2 % of the frame time); (1) render_fused_kernel<whole> (fused=True / "
+                    "IDN_FUSED_MARCH=1): one launch per 32768-ray chunk, nothing per-sample crosses HBM -- but every change of network re-fetches a "
+                    "2.4 MB weight stream into each XCD's L2 (the two streams are 4.7 MB against 4 MiB), more HBM traffic than (0) moves; (2) the same "
+                    "kernel as two launches, one network each (fused='split' / IDN_FUSED_MARCH=2): the stream stays in L2 and only the 768 B of fine "
+                    "depths per ray cross HBM.  DESIGN.md section 3")
 
 
 def kernel_source_sha16():
@@ -144,14 +155,15 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(precision, fused=False):
+def pmc_traffic(precision, fused=0):
     """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the process, so the
     figure comes from the newest committed rocprofv3 --pmc summary of this same command for this arithmetic
     (profiles/rNN_pmc_mlp_<prec>_final.json; tools/profile_round.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
     separate passes) -- and only if that summary was taken from the kernel sources that are running now.
     Returns (bytes or None, traffic_source dict)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_render_fused_final.json" if fused else f"r*_pmc_mlp_{precision}_final.json")))
+    stem = f"pmc_{ARRANGEMENT_PMC[int(fused)]}_final.json" if fused else f"pmc_mlp_{precision}_final.json"   # (fused: the fp32 64 + 128 arrangements 1 / 2)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + stem)))
     if not files:
         return None, {"file": None, "reason": "no PMC summary committed for this arithmetic"}
     path = files[-1]
@@ -574,7 +586,7 @@ def main():
     pk_c, pk_f = coarse.packed_weights(), fine.packed_weights()
     prec, prec_f = coarse.prec_code, fine.prec_code
 
-    fused_headline = bool(ops.FUSED_MARCH_DEFAULT and args.precision == "f32" and S == 64 and Ni == 128)   # what fused=None resolves to below
+    fused_headline = ops.FUSED_MARCH_DEFAULT if (args.precision == "f32" and S == 64 and Ni == 128) else 0   # what fused=None resolves to below (0 / 1 / 2)
     collective = dist_on()   # world > 1, or the one-rank RCCL communicator of IDN_DIST_INIT_WORLD1=1 (the collective then runs at world size 1)
     marks = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
@@ -644,7 +656,7 @@ def main():
         ach = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12 if k_ms.value > 0 else None
         peaks = mode_peaks()
         peak = peaks[args.precision]
-        kname = {"f32": KNAME_FUSED if fused_headline else KNAME_SEQ,
+        kname = {"f32": KNAME[fused_headline],
                  "bf16x3": "idn::mlp_bf16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 bf16 MFMAs per product)",
                  "bf16": "idn::mlp_bf16_kernel<kModeRays> (fused PE + FaceNeRF MLP, plain bf16 MFMA)",
                  "fp16x3": "idn::mlp_fp16x3_kernel<kModeRays> (fused PE + FaceNeRF MLP, 3 fp16 MFMAs per product)",
@@ -719,38 +731,37 @@ def main():
                     "note": notes[other]}
             set_mode(args.precision)
             if args.precision == "f32" and S == 64 and Ni == 128:
-                # the OTHER arrangement of the same arithmetic on the same frame, after the timed region (same pixels, bit for bit):
-                # north_star's fused ray-march kernel (csrc/render_fused.hip: both networks, the march and the final compositing as
-                # ONE launch, a ray's depths / raw outputs / weights / cdf in LDS) beside the default kernel sequence -- or the
-                # sequence beside it when the process runs with IDN_FUSED_MARCH=1
-                def step_alt():
-                    rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0, device=dev)
-                    return ops.render_rays_fwd(rays, bc, pk_c, coarse.folded_bias(aud, expr, latent), pk_f, fine.folded_bias(aud, expr, latent),
-                                               t_vals, u, Ni, precision=prec, precision_fine=prec_f, fused=not fused_headline)
-                with torch.no_grad():
-                    step_alt()
-                    torch.cuda.synchronize()
-                    lib.idealnerf_profile_begin()
-                    t1 = time.perf_counter()
-                    for _ in range(2):
-                        q_out = step_alt()
-                    torch.cuda.synchronize()
-                    d_q = time.perf_counter() - t1
-                lib.idealnerf_profile_end(C.byref(k_ms), C.byref(k_n), C.byref(k_pts))
-                a_q = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12
-                res["kernel_sequence_mode" if fused_headline else "fused_march"] = {
-                    "value": H * W * (S + S + Ni) * 2 / d_q, "unit": "ray-samples/s", "ms_per_step": d_q / 2 * 1e3,
-                    "ratio_to_headline": (H * W * (S + S + Ni) * 2 / d_q) / value,
-                    "identical_to_headline_frame": bool(torch.equal(q_out["rgb_map"].reshape(-1, 3), tile.reshape(-1, 3))),
-                    "roofline": {"bound": "mfma", "kernel": KNAME_SEQ if fused_headline else KNAME_FUSED,
-                                 "achieved": a_q, "peak": peaks["f32"], "unit": "TFLOP/s", "frac": a_q / peaks["f32"],
-                                 "launches": k_n.value, "avg_launch_ms": (k_ms.value / k_n.value) if k_n.value else None,
-                                 "traffic": pmc_traffic("f32", fused=not fused_headline)[0]},
-                    "note": "the two arrangements: (a) the kernel sequence mlp_f32_kernel -> march_kernel -> mlp_f32_kernel -> composite_kernel "
-                            "(default; raw network outputs and fine depths cross HBM: 40 B per sample, 0.2 % of the frame time); (b) "
-                            "render_fused_kernel (fused=True / IDN_FUSED_MARCH=1): one launch per 32768-ray chunk, nothing per-sample crosses "
-                            "HBM -- but every change of network re-fetches a 2.4 MB weight stream into each XCD's L2 (the two streams are 4.7 MB "
-                            "against 4 MiB), which is more HBM traffic than (a) saves: DESIGN.md section 3"}
+                # the OTHER arrangements of the same arithmetic on the same frame, after the timed region (same pixels, bit for bit):
+                # 0 the kernel sequence; 1 north_star's fused ray-march kernel (csrc/render_fused.hip: both networks, the march and
+                # the final compositing as ONE launch, a ray's depths / raw outputs / weights / cdf in LDS); 2 the same kernel as two
+                # launches (coarse network + march | fine network + compositing), only the fine depths crossing HBM
+                for arr in (0, 1, 2):
+                    if arr == fused_headline:
+                        continue
+                    def step_alt():
+                        rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0, device=dev)
+                        return ops.render_rays_fwd(rays, bc, pk_c, coarse.folded_bias(aud, expr, latent), pk_f, fine.folded_bias(aud, expr, latent),
+                                                   t_vals, u, Ni, precision=prec, precision_fine=prec_f, fused=arr)
+                    with torch.no_grad():
+                        step_alt()
+                        torch.cuda.synchronize()
+                        lib.idealnerf_profile_begin()
+                        t1 = time.perf_counter()
+                        for _ in range(2):
+                            q_out = step_alt()
+                        torch.cuda.synchronize()
+                        d_q = time.perf_counter() - t1
+                    lib.idealnerf_profile_end(C.byref(k_ms), C.byref(k_n), C.byref(k_pts))
+                    a_q = (k_pts.value * FLOP_PER_SAMPLE) / (k_ms.value * 1e-3) / 1e12
+                    res[ARRANGEMENT_BLOCK[arr]] = {
+                        "value": H * W * (S + S + Ni) * 2 / d_q, "unit": "ray-samples/s", "ms_per_step": d_q / 2 * 1e3,
+                        "ratio_to_headline": (H * W * (S + S + Ni) * 2 / d_q) / value,
+                        "identical_to_headline_frame": bool(torch.equal(q_out["rgb_map"].reshape(-1, 3), tile.reshape(-1, 3))),
+                        "roofline": {"bound": "mfma", "kernel": KNAME[arr],
+                                     "achieved": a_q, "peak": peaks["f32"], "unit": "TFLOP/s", "frac": a_q / peaks["f32"],
+                                     "launches": k_n.value, "avg_launch_ms": (k_ms.value / k_n.value) if k_n.value else None,
+                                     "traffic": pmc_traffic("f32", fused=arr)[0]},
+                        "note": ARRANGEMENT_NOTE}
         if world == 1 and not args.no_f32_mode:
             res["network_api"] = network_api_measurement(args, syn, coarse, fine, value, tile)
             res["network_api_perturb1"] = network_api_measurement(args, syn, coarse, fine, value, tile, frames=2, perturb=1.0)

@@ -365,6 +365,7 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
     const size_t need = idealnerf_render_workspace_bytes(n, S, Ni);
     if (!a->workspace || a->workspace_bytes < need)
         return fail(IDN_EWORKSPACE, "workspace %zu bytes < required %zu", a->workspace_bytes, need);
+    if (a->fused_march != 0 && a->fused_march != 1 && a->fused_march != 2) return fail(IDN_EINVAL, "fused_march %d (0 = kernel sequence, 1 = one kernel, 2 = two kernels)", a->fused_march);
     if (a->fused_march) {
         if (a->precision != IDN_PREC_F32 || prec_fine != IDN_PREC_F32) return fail(IDN_EUNSUPPORTED, "fused march: built for the fp32 arithmetic");
         if (S != 64 || Ni != 128) return fail(IDN_EUNSUPPORTED, "fused march: built for n_samples = 64, n_importance = 128 (got %d, %d)", S, Ni);
@@ -407,11 +408,15 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
             fo.rgb_fg = off(a->rgb_fg, r0 * 3);
             fo.last_weight = off(a->last_weight, r0);
             const float* u = a->u_per_ray ? a->u + r0 * Ni : a->u;
-            if (int e = launch_render_fused(a->packed_coarse, a->folded_coarse, a->packed_fine, a->folded_fine, rays, bc, w.z_c, u, a->u_per_ray, c,
-                                            a->white_bkgd, co, fo, off(a->z_std, r0), off(a->tap_raw_coarse, r0 * S * 4), off(a->tap_raw_fine, r0 * Sf * 4),
-                                            off(a->tap_z_fine, r0 * Sf), off(a->tap_inds, r0 * Ni), off(a->tap_z_samples, r0 * Ni),
+            const bool split = a->fused_march == 2;   // two launches: the fine depths cross HBM (w.z_f), everything else stays on chip
+            if (int e = launch_render_fused(a->fused_march, a->packed_coarse, a->folded_coarse, a->packed_fine, a->folded_fine, rays, bc, w.z_c,
+                                            split ? w.z_f : nullptr, u, a->u_per_ray, c, a->white_bkgd, co, fo, off(a->z_std, r0),
+                                            off(a->tap_raw_coarse, r0 * S * 4), off(a->tap_raw_fine, r0 * Sf * 4),
+                                            split ? nullptr : off(a->tap_z_fine, r0 * Sf), off(a->tap_inds, r0 * Ni), off(a->tap_z_samples, r0 * Ni),
                                             off(a->tap_cdf, r0 * (S - 1)), st))
                 return e;
+            if (split)
+                if (int e = tap(off(a->tap_z_fine, r0 * Sf), w.z_f, (size_t)c * Sf * 4)) return e;
             continue;
         }
         if (int e = tap(off(a->tap_raw_coarse, r0 * S * 4), w.raw_c, (size_t)c * S * 16)) return e;

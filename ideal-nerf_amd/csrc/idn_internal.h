@@ -220,9 +220,10 @@ int launch_composite(const float* raw, const float* z, const float* rays, const 
 int launch_march(const float* raw, const float* z, const float* rays, const float* bc, const float* noise, int white_bkgd,
                  const idn_composite_out& out, const float* u, int u_per_ray, int64_t n_rays, int S, int Ni,
                  float* z_samples, int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s);
-// render_fused.hip: coarse network -> march -> fine network -> compositing in one kernel (fp32, S = 64, Ni = 128)
-int launch_render_fused(const float* packed_c, const float* folded_c, const float* packed_f, const float* folded_f,
-                        const float* rays, const float* bc, const float* z_c, const float* u, int u_per_ray, int64_t n_rays,
+// render_fused.hip (fp32, S = 64, Ni = 128).  arrangement 1: coarse network -> march -> fine network -> compositing in ONE kernel;
+// 2: coarse network + march | fine network + compositing (two launches, the fine depths z_f[n, 192] cross HBM between them)
+int launch_render_fused(int arrangement, const float* packed_c, const float* folded_c, const float* packed_f, const float* folded_f,
+                        const float* rays, const float* bc, const float* z_c, float* z_f, const float* u, int u_per_ray, int64_t n_rays,
                         int white_bkgd, const idn_composite_out& co, const idn_composite_out& fo, float* z_std, float* tap_raw_c,
                         float* tap_raw_f, float* tap_z_fine, int64_t* tap_inds, float* tap_z_samples, float* tap_cdf, hipStream_t s);
 int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in, const float* bins_in,

@@ -58,16 +58,33 @@ struct FusedArgs {
     int64_t* tap_inds;
     float* tap_z_samples;
     float* tap_cdf;
+    float* z_f;          // [n, 192] fine depths in HBM: written by the coarse half, read by the fine half (split arrangement only)
 };
 
 using WStreamDual = WStreamT<4, kSliceFrags, kRingSlots, true>;
 
+// PHASE: kFusedWhole = the whole ray in one launch; kFusedCoarse = coarse network + march (fine depths -> a.z_f);
+// kFusedFine = fine network + compositing (fine depths <- a.z_f).  The two halves together are the SPLIT arrangement: one
+// network per launch, so the weight stream stays in L2 like in the kernel sequence, and still no raw output, weight or cdf in
+// HBM -- only the 768 bytes of fine depths per ray cross between the launches.
+enum { kFusedWhole = 0, kFusedCoarse = 1, kFusedFine = 2 };
+template <int PHASE>
+constexpr int fused_lds() {
+    return kRingFrags * kFragBytes + kFBiasPadFloats * 4 + (PHASE == kFusedWhole ? kFG * kFSf * 4 : 0) +
+           (PHASE == kFusedCoarse ? kFG * kFS * 16 + 4 * kFScratchFloats * 4 : kFUnionBytes);
+}
+static_assert(fused_lds<kFusedWhole>() == kFusedLds, "LDS layout");
+
+template <int PHASE>
 __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
+    constexpr bool kWhole = PHASE == kFusedWhole;
+    constexpr int kP0 = PHASE == kFusedFine ? kFCoarsePasses : 0;                 // this launch's passes of a group: [kP0, kP1)
+    constexpr int kP1 = PHASE == kFusedCoarse ? kFCoarsePasses : kFPasses;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     float* bias_s = reinterpret_cast<float*>(smem + kRingFrags * kFragBytes);
-    float* zf_s = bias_s + kFBiasPadFloats;
-    char* uni = reinterpret_cast<char*>(zf_s + kFG * kFSf);
+    float* zf_s = bias_s + kFBiasPadFloats;                                        // (whole-ray arrangement only)
+    char* uni = reinterpret_cast<char*>(zf_s + (kWhole ? kFG * kFSf : 0));
     float4* rawf_s = reinterpret_cast<float4*>(uni);
     float4* rawc_s = reinterpret_cast<float4*>(uni);
 
@@ -78,9 +95,10 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
     float* scratch = reinterpret_cast<float*>(uni + kFG * kFS * 16) + wave * kFScratchFloats;
 
     Diag dg;
-    WStreamDual ws;
+    std::conditional_t<kWhole, WStreamDual, WStream> ws;
     ws.dg = &dg;
-    ws.init_dual(a.wstream_c, a.wstream_f, kFCoarsePasses, kFPasses, kNumSlices, ring, tid, wave);
+    if constexpr (kWhole) ws.init_dual(a.wstream_c, a.wstream_f, kFCoarsePasses, kFPasses, kNumSlices, ring, tid, wave);
+    else ws.init(PHASE == kFusedCoarse ? a.wstream_c : a.wstream_f, kNumSlices, ring, tid, wave);
     PeLane pln;
     pln.init(h);
     FragReader fr;
@@ -102,7 +120,8 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
         in.f[0] = rr[0]; in.f[1] = rr[1]; in.f[2] = rr[2];
         in.f[3] = rr[3]; in.f[4] = rr[4]; in.f[5] = rr[5];
         in.f[6] = rr[8]; in.f[7] = rr[9]; in.f[8] = rr[10];
-        in.f[9] = fine ? 0.0f : a.z_c[ray * kFS + (q & 63)];   // (fine depths come from LDS when the pass starts)
+        if constexpr (kWhole) in.f[9] = fine ? 0.0f : a.z_c[ray * kFS + (q & 63)];   // (fine depths come from LDS when the pass starts)
+        else in.f[9] = fine ? a.z_f[ray * kFSf + q % kFSf] : a.z_c[ray * kFS + (q & 63)];
     };
 
     // The folded bias block of the network in use sits in LDS (there is no room for both).  At a change of network the other
@@ -122,23 +141,24 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
     auto bias_commit = [&]() {
         static_for<kFBiasPerThread>([&](auto I) { bias_s[tid + 256 * decltype(I)::value] = bias_next[decltype(I)::value]; });
     };
-    bias_fetch(a.bias_c);
+    bias_fetch(PHASE == kFusedFine ? a.bias_f : a.bias_c);
     bias_commit();
     __syncthreads();
 
     PointIn cur, nxt;
-    load_in(blockIdx.x, 0, cur);
+    load_in(blockIdx.x, kP0, cur);
     nxt = cur;
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
 #pragma unroll 1
-        for (int pass = 0; pass < kFPasses; ++pass) {
+        for (int pass = kP0; pass < kP1; ++pass) {
             // (the pass number as an opaque scalar: left visible, hipcc peels and specialises the loop on it -- four copies of
             //  the 1 680-MFMA pass body and 21 spilled registers)
             int p = pass;
             asm volatile("" : "+s"(p));
             const bool fine = p >= kFCoarsePasses;
             const int q = point_q(p);
-            if (fine) cur.f[9] = zf_s[q];   // row q / 192, sample q % 192: the rows are contiguous
+            if constexpr (kWhole)
+                if (fine) cur.f[9] = zf_s[q];   // row q / 192, sample q % 192: the rows are contiguous
 
             // ---- inputs: this lane's half of the 64 point features and 32 direction features
             float pe[8][4], pd[4][4];
@@ -162,10 +182,10 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
             float rgb[3], sigma;
             f32_inference_pass(pe, pd, bias_s, bias_h, ws, fr,
                                [&]() {
-                                   const bool wraps = p + 1 == kFPasses;
+                                   const bool wraps = p + 1 == kP1;
                                    long gn = wraps ? g + gridDim.x : g;
                                    if (gn >= ngroups) gn = g;   // no next group: a valid, unused address
-                                   load_in(gn, wraps ? 0 : p + 1, nxt);
+                                   load_in(gn, wraps ? kP0 : p + 1, nxt);
                                },
                                [&]() { touch_point(nxt); }, rgb, sigma);
 
@@ -181,11 +201,11 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
             cur = nxt;
 
             // ---- between the networks: wave w marches ray w of the group
-            if (p == kFCoarsePasses - 1) {
+            if (PHASE != kFusedFine && p == kFCoarsePasses - 1) {
                 __syncthreads();   // (also: every wave is done with the coarse bias block)
-                bias_fetch(a.bias_f);
+                if constexpr (kWhole) bias_fetch(a.bias_f);
                 const long ray = g * kFG + wave;
-                float* zrow = zf_s + wave * kFSf;
+                float* zrow = kWhole ? zf_s + wave * kFSf : nullptr;   // split arrangement: the fine depths go to a.z_f only
                 if (ray < a.n_rays) {   // wave-uniform
                     float* cdf = scratch;
                     float* bins = scratch + 64;
@@ -196,24 +216,25 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
                     wrow[lane] = wts[0];
                     wave_lds_fence();
                     const SampleArgs sa{a.z_c, nullptr, nullptr, nullptr, a.u, a.u_per_ray, a.n_rays, kFS, kFNi, kFS - 1,
-                                        a.tap_z_samples, a.tap_inds, a.tap_cdf, a.tap_z_fine, a.z_std};
+                                        a.tap_z_samples, a.tap_inds, a.tap_cdf, kWhole ? a.tap_z_fine : a.z_f, a.z_std};
                     sample_pdf_ray(sa, ray, lane, cdf, bins, val, wrow, zrow);
-                } else {
+                } else if constexpr (kWhole) {
                     for (int k = lane; k < kFSf; k += 64) zrow[k] = 0.0f;   // a padding ray: its points are computed and dropped
                 }
-                bias_commit();
+                if constexpr (kWhole) bias_commit();
                 __syncthreads();
             }
             // ---- after the fine passes: wave w composites ray w
-            if (p == kFPasses - 1) {
+            if (PHASE != kFusedCoarse && p == kFPasses - 1) {
                 __syncthreads();   // (also: every wave is done with the fine bias block)
-                bias_fetch(a.bias_c);
+                if constexpr (kWhole) bias_fetch(a.bias_c);
                 const long ray = g * kFG + wave;
                 if (ray < a.n_rays) {
                     float wts[3];
-                    composite_ray<3>(rawf_s + wave * kFSf, zf_s + wave * kFSf, a.rays, a.bc, ray, lane, kFSf, nullptr, a.white_bkgd, a.fo, wts);
+                    composite_ray<3>(rawf_s + wave * kFSf, kWhole ? zf_s + wave * kFSf : a.z_f + ray * kFSf, a.rays, a.bc, ray, lane, kFSf, nullptr,
+                                     a.white_bkgd, a.fo, wts);
                 }
-                bias_commit();
+                if constexpr (kWhole) bias_commit();
                 __syncthreads();
             }
         }
@@ -223,24 +244,36 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
     __syncthreads();
 }
 
-int launch_render_fused(const float* packed_c, const float* folded_c, const float* packed_f, const float* folded_f,
-                        const float* rays, const float* bc, const float* z_c, const float* u, int u_per_ray, int64_t n_rays,
+int launch_render_fused(int arrangement, const float* packed_c, const float* folded_c, const float* packed_f, const float* folded_f,
+                        const float* rays, const float* bc, const float* z_c, float* z_f, const float* u, int u_per_ray, int64_t n_rays,
                         int white_bkgd, const idn_composite_out& co, const idn_composite_out& fo, float* z_std, float* tap_raw_c,
                         float* tap_raw_f, float* tap_z_fine, int64_t* tap_inds, float* tap_z_samples, float* tap_cdf, hipStream_t s) {
     if (n_rays <= 0) return IDN_OK;
+    if (arrangement != 1 && arrangement != 2) return fail(IDN_EINVAL, "fused march: arrangement %d (1 = one kernel, 2 = coarse + march | fine + compositing)", arrangement);
     static LaunchSetup setup;
     int num_cu = 0;
     if (int e = setup.get([]() -> int {
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<kFusedWhole>), hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds<kFusedWhole>()));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<kFusedCoarse>), hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds<kFusedCoarse>()));
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<kFusedFine>), hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds<kFusedFine>()));
             return IDN_OK;
         }, &num_cu))
         return e;
     const int64_t ngroups = (n_rays + kFG - 1) / kFG;
     const int grid = (int)(ngroups < num_cu ? ngroups : num_cu);
     FusedArgs a{packed_c, folded_c, packed_f, folded_f, rays, bc, z_c, u, u_per_ray, (long)n_rays, white_bkgd, co, fo, z_std,
-                tap_raw_c, tap_raw_f, tap_z_fine, tap_inds, tap_z_samples, tap_cdf};
-    ProfScope prof(s, n_rays * (kFS + kFSf), IDN_PROF_MLP_FWD);
-    hipLaunchKernelGGL(render_fused_kernel, dim3(grid), dim3(256), kFusedLds, s, a);
+                tap_raw_c, tap_raw_f, tap_z_fine, tap_inds, tap_z_samples, tap_cdf, z_f};
+    if (arrangement == 1) {
+        ProfScope prof(s, n_rays * (kFS + kFSf), IDN_PROF_MLP_FWD);
+        hipLaunchKernelGGL(render_fused_kernel<kFusedWhole>, dim3(grid), dim3(256), fused_lds<kFusedWhole>(), s, a);
+    } else {
+        {
+            ProfScope prof(s, n_rays * kFS, IDN_PROF_MLP_FWD);
+            hipLaunchKernelGGL(render_fused_kernel<kFusedCoarse>, dim3(grid), dim3(256), fused_lds<kFusedCoarse>(), s, a);
+        }
+        ProfScope prof(s, n_rays * kFSf, IDN_PROF_MLP_FWD);
+        hipLaunchKernelGGL(render_fused_kernel<kFusedFine>, dim3(grid), dim3(256), fused_lds<kFusedFine>(), s, a);
+    }
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

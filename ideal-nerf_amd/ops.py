@@ -367,14 +367,15 @@ def _workspace(nbytes: int, device, stream) -> torch.Tensor:
     return ws
 
 
-FUSED_MARCH_DEFAULT = os.environ.get("IDN_FUSED_MARCH", "0") == "1"   # read once: 1 = the one-kernel ray path wherever it applies
+FUSED_MARCH_DEFAULT = int(os.environ.get("IDN_FUSED_MARCH", "0"))   # read once: the arrangement of the fp32 64 + 128 path where `fused` is not given (0 sequence, 1 one kernel, 2 two kernels)
 
 
 def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, n_importance,
                     t_rand=None, with_fg=False, taps=False, precision=IDN_PREC_F32, precision_fine=None, lindisp=False,
                     white_bkgd=False, noise_coarse=None, noise_fine=None, fused=None) -> Dict[str, torch.Tensor]:
     """Network.render_rays forward (audio_exp_nerf.py:297-371) as one C call.  `precision_fine` (default: the
-    same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it.  `fused=True`: the
+    same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it.  `fused="split"` (or 2):
+    two launches -- coarse network + march | fine network + compositing -- with only the fine depths crossing HBM.  `fused=True`: the
     whole path as ONE kernel with a ray's samples, raw outputs and weights in LDS (csrc/render_fused.hip; fp32, 64 + 128
     samples, no density noise -- anything else raises); `fused=False`: the kernel sequence (network, march, network,
     compositing).  Same results bit for bit, same speed to 0.1 % on a full frame; the sequence moves less data (the fused kernel re-fetches
@@ -422,9 +423,10 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
         a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
         a.noise_coarse, a.noise_fine = _ptr(noise_coarse, "noise_coarse"), _ptr(noise_fine, "noise_fine")
         if fused is None:
-            fused = (FUSED_MARCH_DEFAULT and S == 64 and Ni == 128 and noise_coarse is None and noise_fine is None and
-                     _precision(precision) == IDN_PREC_F32 and (precision_fine is None or _precision(precision_fine) == IDN_PREC_F32))
-        a.fused_march = int(bool(fused))
+            applies = (S == 64 and Ni == 128 and noise_coarse is None and noise_fine is None and
+                       _precision(precision) == IDN_PREC_F32 and (precision_fine is None or _precision(precision_fine) == IDN_PREC_F32))
+            fused = FUSED_MARCH_DEFAULT if applies else 0
+        a.fused_march = 2 if fused == "split" else int(fused)   # False / 0: sequence, True / 1: one kernel, "split" / 2: two kernels
         for k, v in out.items():
             setattr(a, k, v.data_ptr())
         nbytes = lib.idealnerf_render_workspace_bytes(n, S, Ni)

@@ -1498,11 +1498,12 @@ def test_fused_ray_kernel_equals_the_unfused_path(idn, dev, n_rays, jitter, with
         # (the reference leaves white_bkgd and lindisp off; the one-kernel path takes them like the sequence does)
         kw = dict(t_rand=t_rand, with_fg=with_fg, taps=taps, white_bkgd=not taps, lindisp=jitter and not taps)
         seq = idn.ops.render_rays_fwd(*args, fused=False, **kw)
-        one = idn.ops.render_rays_fwd(*args, fused=True, **kw)
-        assert sorted(seq) == sorted(one)
-        for k in seq:
-            assert torch.isfinite(seq[k].float()).all(), k
-            assert torch.equal(seq[k], one[k]), f"{k}: fused != kernel sequence (max diff {(seq[k].double() - one[k].double()).abs().max().item():.3e})"
+        for how in (True, "split"):   # one launch; two launches (coarse + march | fine + compositing, the fine depths through HBM)
+            one = idn.ops.render_rays_fwd(*args, fused=how, **kw)
+            assert sorted(seq) == sorted(one)
+            for k in seq:
+                assert torch.isfinite(seq[k].float()).all(), k
+                assert torch.equal(seq[k], one[k]), f"{k}: fused={how!r} != kernel sequence (max diff {(seq[k].double() - one[k].double()).abs().max().item():.3e})"
     # what the fused kernel is not built for is refused, not approximated
     with pytest.raises(idn._lib.IdealNerfError, match="fused march"):
         idn.ops.render_rays_fwd(r, bc, pk_c, fold_c(*cond), pk_f, fold_f(*cond), torch.linspace(0.0, 1.0, 32).to(dev), u, 128, fused=True)

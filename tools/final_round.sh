@@ -20,6 +20,11 @@ IDN_FUSED_MARCH=1 IDN_PROFILE_KERNEL=render_fused_kernel bash tools/profile_roun
 cp gpurun_out/prof_f32/pmc_summary.json $F/pmc_render_fused_final.json
 cp gpurun_out/prof_f32/kernel_stats.csv $F/kernel_stats_render_fused_final.csv
 echo "profile render_fused done"
+# ... and as two launches (coarse network + march | fine network + compositing): both instances of the kernel, mean per launch
+IDN_FUSED_MARCH=2 IDN_PROFILE_KERNEL=render_fused_kernel bash tools/profile_round.sh f32 > $F/profile_render_split.log 2>&1
+cp gpurun_out/prof_f32/pmc_summary.json $F/pmc_render_split_final.json
+cp gpurun_out/prof_f32/kernel_stats.csv $F/kernel_stats_render_split_final.csv
+echo "profile render_split done"
 for P in f32 bf16x6; do
   bash tools/profile_round.sh $P > $F/profile_$P.log 2>&1
   cp gpurun_out/prof_$P/pmc_summary.json $F/pmc_mlp_${P}_final.json
@@ -36,6 +41,7 @@ if [ -f ideal-nerf_amd/libidealnerf_wrap.so ]; then bash tools/ab_bench.sh wrap 
 mkdir -p profiles
 for P in f32 bf16x6; do cp $F/pmc_mlp_${P}_final.json profiles/${ROUND:-r03}_pmc_mlp_${P}_final.json; done
 cp $F/pmc_render_fused_final.json profiles/${ROUND:-r03}_pmc_render_fused_final.json
+cp $F/pmc_render_split_final.json profiles/${ROUND:-r03}_pmc_render_split_final.json
 python bench.py > $F/bench_default.json 2> $F/bench_default.err
 python bench.py --precision bf16x6 --no-cpu-baseline > $F/bench_bf16x6.json 2>> $F/bench_default.err
 python bench.py --workload train --steps 12 --warmup 4 > $F/bench_train.json 2>> $F/bench_default.err
