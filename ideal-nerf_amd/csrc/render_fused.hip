@@ -15,10 +15,12 @@
 // prefetch wraps, so the first slice of the next pass's network is in flight during the last slice of this pass), and the
 // folded bias block in LDS is exchanged at the two network changes of a group, its fetch hidden under the march / the compositing.
 //
-// Same arithmetic as the three-kernel path (mlp_f32_kernel -> march_kernel -> mlp_f32_kernel -> composite_kernel), bit
-// for bit: tests/test_hip_parity.py::test_fused_ray_kernel_equals_the_unfused_path.  It is NOT the default
-// ("ns1"): with one wave per SIMD nothing hides the latency of the march, during which the matrix
-// pipe idles, and the 40 bytes per sample it keeps out of HBM were 0.2 % of the frame time.
+// Same arithmetic as the kernel sequence (mlp_f32_kernel -> march_kernel -> mlp_f32_kernel -> composite_kernel), bit for bit:
+// tests/test_hip_parity.py::test_fused_ray_kernel_equals_the_unfused_path.  The same kernel also runs as TWO launches
+// (PHASE: coarse network + march | fine network + compositing), one network each, with the fine depths through HBM.
+// Measured: one launch is the fastest arrangement on a full frame (1.000-1.005 of the sequence) but moves
+// six times its HBM bytes -- two 2.25 MiB streams alternate through a 4 MiB L2 --; two launches move half the sequence's bytes
+// at 0.995 of its speed.  The sequence stays the default; these are options (idn_render_args::fused_march = 1 / 2).
 #include "march.h"
 #include "mlp_f32_layers.h"
 
@@ -250,6 +252,7 @@ int launch_render_fused(int arrangement, const float* packed_c, const float* fol
                         float* tap_raw_f, float* tap_z_fine, int64_t* tap_inds, float* tap_z_samples, float* tap_cdf, hipStream_t s) {
     if (n_rays <= 0) return IDN_OK;
     if (arrangement != 1 && arrangement != 2) return fail(IDN_EINVAL, "fused march: arrangement %d (1 = one kernel, 2 = coarse + march | fine + compositing)", arrangement);
+    if (arrangement == 2 && !z_f) return fail(IDN_EINVAL, "fused march: the two-launch arrangement needs the fine-depth buffer z_f[n, 192]");
     static LaunchSetup setup;
     int num_cu = 0;
     if (int e = setup.get([]() -> int {
