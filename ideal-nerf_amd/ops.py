@@ -374,13 +374,14 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
                     t_rand=None, with_fg=False, taps=False, precision=IDN_PREC_F32, precision_fine=None, lindisp=False,
                     white_bkgd=False, noise_coarse=None, noise_fine=None, fused=None) -> Dict[str, torch.Tensor]:
     """Network.render_rays forward (audio_exp_nerf.py:297-371) as one C call.  `precision_fine` (default: the
-    same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it.  `fused="split"` (or 2):
-    two launches -- coarse network + march | fine network + compositing -- with only the fine depths crossing HBM.  `fused=True`: the
-    whole path as ONE kernel with a ray's samples, raw outputs and weights in LDS (csrc/render_fused.hip; fp32, 64 + 128
-    samples, no density noise -- anything else raises); `fused=False`: the kernel sequence (network, march, network,
-    compositing).  Same results bit for bit, same speed to 0.1 % on a full frame; the sequence moves less data (the fused kernel re-fetches
-    a network's 2.4 MB weight stream into every L2 at each change of network) and is the default.  `fused=None`: the
-    kernel sequence, or the fused kernel wherever it applies when the process was started with IDN_FUSED_MARCH=1."""
+    same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it.
+    `fused`: the arrangement of the kernels (same results bit for bit).  False / 0: the kernel sequence
+    (network, march, network, compositing) -- the default.  True / 1: the whole path as ONE kernel with a ray's samples, raw
+    outputs, weights and cdf in LDS (csrc/render_fused.hip): 0-0.5 % faster on a full frame, six times the HBM bytes (it
+    re-fetches a network's 2.4 MB weight stream into every L2 at each change of network).  "split" / 2: the same kernel as
+    two launches (coarse network + march | fine network + compositing): half the sequence's bytes, 0.5 % slower.  1 and 2 are
+    built for fp32, 64 + 128 samples, no density noise -- anything else raises.  None: IDN_FUSED_MARCH (0 / 1 / 2, read once)
+    wherever the fused kernel applies, else the sequence."""
     lib = _lib.load()
     _shape(rays, "rays", None, RAY_FLOATS)
     _shape(t_vals, "t_vals", None)

@@ -248,10 +248,11 @@ typedef struct idn_render_args {
     const float* noise_fine;   /* [n, n_samples + n_importance] or NULL */
     /* 0: the kernel sequence (network, march, network, compositing; raw outputs and fine depths through HBM).
      * 1: the whole per-ray path as ONE kernel that keeps a ray's sample positions, raw network outputs, weights and cdf in
-     *    LDS -- nothing per-sample crosses HBM (csrc/render_fused.hip); as fast as the sequence on a full frame, but it
+     *    LDS -- nothing per-sample crosses HBM (csrc/render_fused.hip); 0-0.5 % faster than the sequence on a full frame, but it
      *    re-fetches a network's weight stream into every L2 at each change of network (six times the sequence's HBM bytes).
      * 2: the same kernel as two launches -- coarse network + march | fine network + compositing: one network per launch,
-     *    so the weight stream stays in L2, and only the 768 bytes of fine depths per ray cross HBM between the launches.
+     *    so the weight stream stays in L2, and only the 768 bytes of fine depths per ray cross HBM between the launches
+     *    (half the sequence's HBM bytes, 0.5 % slower).
      * 1 and 2 give the sequence's results bit for bit; they are built for the fp32 arithmetic at n_samples = 64,
      * n_importance = 128 without density noise (anything else returns IDN_EUNSUPPORTED).  DESIGN.md section 3. */
     int fused_march;
