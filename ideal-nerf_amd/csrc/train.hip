@@ -373,8 +373,8 @@ __device__ __forceinline__ void x6_retire(X6Frag (&f)[3]) {
     asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f[0].v), "+v"(f[1].v), "+v"(f[2].v) : "n"(N) : "memory");
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char x6_smem[];
+// One 256 x 256 product (one split of the points) of the batch below.
+__device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, char* x6_smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hh = lane >> 5;
@@ -558,6 +558,10 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNArgs g) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    // the clamped re-reads of the last chunk are still in flight into ra / rb: retired here, so that the next item of a batch
+    // starts on registers nothing is about to write (the stores below then drain under that item's first loads)
+#pragma unroll
+    for (int p = 0; p < kTnRows; ++p) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[p]), "+v"(rb[p])::"memory");
     if (do_colsum) g.cpart[(long)split * g.N + tid] = csum + csum1;
     // lane (i, hh), tile (x, y), register r: output (32 (4 wr + x) + d_row(r, hh), 32 (4 wc + y) + i)
     float* out = g.part + (long)split * g.N * g.K;
@@ -568,6 +572,20 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 out[(long)(32 * (4 * wr + x) + d_row(r, hh)) * g.K + 32 * (4 * wc + y) + i] = acc[x][y][r];
+}
+// The 256 x 256 weight-gradient products of a pass as ONE launch: every workgroup (= one split of the points) walks the
+// items in turn.  They were nine dependent launches per pass (each ~0.2 ms, with a dispatch gap and a ramp between them);
+// inside one kernel an item's 256 KB of partial sums drain while the next item's first chunks are already loading.  Every
+// wave has passed the last chunk barrier of an item before anything of the next one is written to LDS.
+constexpr int kMaxTnBatch = 12;
+struct TNBatch {
+    TNArgs it[kMaxTnBatch];
+    int n;
+};
+__global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNBatch b) {
+    extern __shared__ __attribute__((aligned(16))) char x6_smem[];
+#pragma unroll 1
+    for (int l = 0; l < b.n; ++l) gemm_tn_x6_item(b.it[l], x6_smem);
 }
 
 // out[n*ldo + k] = sum_s part[s][n][k],  n < rows, k < cols  (rows/cols may be smaller than N/K: padding dropped)
@@ -849,7 +867,37 @@ static int env_pipe_f32() {
     return v;
 }
 static int default_gemm_pipe() { return (IDN_DW_X6 && !env_pipe_f32()) ? kPipeX6 : kPipeF32; }
-static int run_tn_partials(const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part,
+// The 256 x 256 bf16-piece products of a pass, collected and launched as one kernel (gemm_tn_x6_kernel walks them)
+struct X6Pending {
+    TNBatch b;
+    int splits = 0;
+    X6Pending() { b.n = 0; }
+    int launch(hipStream_t s) {
+        if (b.n == 0) return IDN_OK;
+        static LaunchSetup setup6;
+        int num_cu = 0;
+        if (int e = setup6.get([]() -> int {
+                IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kX6Lds));
+                return IDN_OK;
+            }, &num_cu))
+            return e;
+        {
+            ProfScope prof(s, b.it[0].P * b.n, IDN_PROF_DW_GEMM_X6);
+            hipLaunchKernelGGL(gemm_tn_x6_kernel, dim3(1, 1, splits), dim3(256), kX6Lds, s, b);
+        }
+        IDN_HIP_CHECK(hipGetLastError());
+        b.n = 0;
+        return IDN_OK;
+    }
+    int add(const TNArgs& g, int item_splits, hipStream_t s) {
+        if (b.n && (b.n == kMaxTnBatch || item_splits != splits || g.P != b.it[0].P))   // (a pass's products all have the pass's points: one batch)
+            if (int e = launch(s)) return e;
+        splits = item_splits;
+        b.it[b.n++] = g;
+        return IDN_OK;
+    }
+};
+static int run_tn_partials(X6Pending& x6, const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part,
                            int* splits_out, hipStream_t s, float* cpart = nullptr, int pipe = -1, const float* B2 = nullptr) {
     if (pipe < 0) pipe = default_gemm_pipe();
     // B2: the x6 kernel's split-B form (two 128-column matrices, B for output columns 0..127 and B2 for 128..255)
@@ -893,16 +941,8 @@ static int run_tn_partials(const float* A, int lda, int N, const float* B, int l
             return IDN_OK;
         }, &num_cu))
         return e;
-    if (ntw == 4 && ktw == 4 && pipe == kPipeX6) {
-        ProfScope prof(s, P, IDN_PROF_DW_GEMM_X6);
-        static LaunchSetup setup6;
-        if (int e = setup6.get([]() -> int {
-                IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kX6Lds));
-                return IDN_OK;
-            }, &num_cu))
-            return e;
-        hipLaunchKernelGGL(gemm_tn_x6_kernel, grid, block, kX6Lds, s, g);
-        IDN_HIP_CHECK(hipGetLastError());
+    if (ntw == 4 && ktw == 4 && pipe == kPipeX6) {   // queued: launched with the pass's other 256 x 256 products (ReduceQueue::flush)
+        if (int e = x6.add(g, splits, s)) return e;
         *splits_out = splits;
         return IDN_OK;
     }
@@ -923,6 +963,7 @@ struct ReduceQueue {
     int blocks = 0;
     float* part_next;    // slab pools of the workspace
     float* cpart_next;
+    X6Pending x6;        // the 256 x 256 bf16-piece products queued so far: one launch, in front of the reductions
     ReduceQueue(float* part_pool, float* cpart_pool) : part_next(part_pool), cpart_next(cpart_pool) { b.n = 0; }
     // out[(0..rows) x (0..cols)] (ld ldo) = sum over splits of the N x K partial blocks, from row row0 / column col0 on
     int add(const float* part, int splits, int N, int K, int row0, int col0, float* out, int ldo, int rows, int cols) {
@@ -932,6 +973,7 @@ struct ReduceQueue {
         return IDN_OK;
     }
     int flush(hipStream_t s) {
+        if (int e = x6.launch(s)) return e;
         if (b.n == 0) return IDN_OK;
         hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, b);
         IDN_HIP_CHECK(hipGetLastError());
@@ -945,7 +987,7 @@ static int run_tn_q(ReduceQueue& q, const float* A, int lda, int N, const float*
                     const float** part_out, const float** cpart_out, bool colsum, hipStream_t s, int pipe, const float* B2 = nullptr) {
     float* part = q.part_next;
     float* cpart = colsum ? q.cpart_next : nullptr;
-    if (int e = run_tn_partials(A, lda, N, B, ldb, K, P, part, splits, s, cpart, pipe, B2)) return e;
+    if (int e = run_tn_partials(q.x6, A, lda, N, B, ldb, K, P, part, splits, s, cpart, pipe, B2)) return e;
     q.part_next += (size_t)(*splits) * N * K;
     if (colsum) q.cpart_next += (size_t)(*splits) * N;
     *part_out = part;
