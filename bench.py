@@ -284,30 +284,38 @@ def bench_rendezvous(args):
 
 
 def bench_train(args):
-    """BASELINE configs[2] as its own line (`--workload train`); the default line carries the same measurement as `train_step`."""
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
-    print(json.dumps(train_measurement(dev, args.steps, args.warmup)))
+    """BASELINE configs[2] as its own line (`--workload train`); the default line carries the same measurement as `train_step`.
+    With N ranks: data-parallel training -- every rank draws its own N_rand rays (weak scaling), the gradients are averaged by
+    ONE bucketed all-reduce per step (parallel.average_gradients, called by train.train_step) and every replica takes the same
+    Adam step.  The reference's counterpart is nn.DataParallel around the Network (distribute_nerf.py:423,457-466)."""
+    world, rank, dev, backend = init_ranks()
+    res = train_measurement(dev, args.steps, args.warmup, world, rank, backend)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist_on():
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
-def train_measurement(dev, steps, warmup):
+def train_measurement(dev, steps, warmup, world=1, rank=0, backend=None):
     """BASELINE configs[2]: May HeadNeRF train step, N_rand=3072 (2432 uniform + 512 mouth box + 128
-    outside the face rect), fwd + bwd + Adam, single GPU.  Secondary measurement; not the headline."""
+    outside the face rect), fwd + bwd + Adam, per GPU.  Secondary measurement; not the headline."""
     import idealnerf_amd
     from idealnerf_amd import synthetic, train as T_
     from idealnerf_amd.audio_exp_nerf import Network
     from idealnerf_amd.helper import RenderConfig
     import numpy as np
     import types
+    import torch.distributed as dist
     args = types.SimpleNamespace(steps=steps, warmup=warmup)
-    torch.manual_seed(0)   # perturb=1 draws the stratified offsets from torch's generator: same run, same loss
+    torch.manual_seed(rank)   # perturb=1 draws the stratified offsets from torch's generator: same run, same loss
     H = W = 450
     syn = synthetic.frame(H, W, seed=0)
     cfg = RenderConfig(perturb=1.0, chunk=8192, near=syn["near"], far=syn["far"])
     net = Network(H, W, syn["focal"], syn["near"], syn["far"], 8192, None, 64, 128, args=cfg).to(dev).train()
     synthetic.xavier_state_dict(net.face_nerf_coarse, 2, 300.0, 0.3)
     synthetic.xavier_state_dict(net.face_nerf_fine, 3, 300.0, 0.3)
-    rs = np.random.RandomState(0)
+    rs = np.random.RandomState(rank)     # every rank samples its own rays of the frame; the weights above are the same everywhere
     uni = rs.choice(H * W, 2432, replace=False)
     yy, xx = np.meshgrid(np.arange(250, 310), np.arange(175, 275), indexing="ij")
     mouth = rs.choice((yy * W + xx).reshape(-1), 512, replace=False)
@@ -324,16 +332,33 @@ def train_measurement(dev, steps, warmup):
     opt = T_.make_optimizer(net, latent_codes)
     data = (batch_rays[None], tgt, bg, auds[None], torch.zeros(1, H, W, 3), pose, syn["expr"][None].to(dev), torch.tensor([3]))
     lib = idealnerf_amd._lib.load()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for i in range(args.warmup):
         T_.train_step(net, opt, data, latent_codes, i, 8)
-    torch.cuda.synchronize()
+    fence()
     lib.idealnerf_profile_begin()
     t0 = time.perf_counter()
     for i in range(args.steps):
         info = T_.train_step(net, opt, data, latent_codes, args.warmup + i, 8)
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
     kinds = profile_kinds(lib)
+    in_sync = None
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # the replicas must still be ONE model: the same gradients and the same Adam step everywhere, bit for bit
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [latent_codes.detach().reshape(-1)])
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
     samples = len(sel) * 256 * args.steps
     # the MFMA kernel families of a step; forward and delta chain count the points they were launched on, the dW
     # GEMMs the step's points (one launch per layer contracts over all of them).  Families on the bf16 pipe compute
@@ -356,8 +381,10 @@ def train_measurement(dev, steps, warmup):
     ach = sum(fl.values()) / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None
     # blended peak of families with different peaks: total FLOP / (sum of each family's ideal time), so frac = ideal / actual
     peak = sum(fl.values()) / sum(fl[k] / peaks[k] for k in fl)
-    return ({"metric": "train ray-samples/sec (N_rand=3072, 64+128, fwd+bwd+Adam)", "value": samples / dt,
-                      "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    return ({"metric": "train ray-samples/sec (N_rand=3072 per GPU, 64+128, fwd+bwd+Adam)", "value": world * samples / dt,
+                      "unit": "ray-samples/s", "n_gpus": world, "ranks": world, "backend": backend,
+                      **({"replicas_in_sync": in_sync, "parallelism": f"dp{world}: one bucketed gradient all-reduce per step"} if world > 1 else {}),
+                      "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f32", "data": "synthetic",
                       "arithmetic": "families named `_x6`: every fp32 operand as the exact sum of three bf16 pieces, six piece products per "
@@ -550,8 +577,6 @@ def main():
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             # plain `python bench.py --gpus N`: this process only starts the ranks (no GPU call before here)
-            if args.workload == "train":
-                ap.error("--workload train is a single-GPU measurement")
             sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")

@@ -31,7 +31,14 @@ def init_weights(m):
 class Network(nn.Module):
     def __init__(self, H, W, focal, near, far, chunk, intrinsic, N_samlpes, N_importance, args: RenderConfig = None):
         super().__init__()
-        self.args = args = args or RenderConfig()
+        # flags: an explicit RenderConfig, or -- the reference's unchanged constructor call -- the process's flags, which
+        # upstream's class reads from its import-time `args` global (audio_exp_nerf.py:25-26,213-226)
+        from . import config
+        if args is None:
+            args = config.default_render_config("head")
+        else:
+            config.check_against_current(args, "head")
+        self.args = args
         self.H, self.W, self.focal, self.near, self.far = H, W, focal, near, far
         self.chunk, self.intrinsic = chunk, intrinsic
         self.N_samples, self.N_importance = N_samlpes, N_importance

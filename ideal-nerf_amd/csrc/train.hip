@@ -344,7 +344,11 @@ typedef int tn_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma_bf16(f32x4 a, f32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tn_bf16x8, a), __builtin_bit_cast(tn_bf16x8, b), c, 0, 0, 0);
 }
-// (low half, high half) = (bf16(x0), bf16(x1)), round to nearest even
+// (low half, high half) = (bf16(x0), bf16(x1)), round to nearest even.
+// The result must NEVER be an MFMA operand directly: an MFMA that reads a register an asm vector instruction wrote fewer
+// than two wait states earlier gets the register's OLD contents, and hipcc puts only `s_nop 0` behind an asm statement
+// (tools/valu_mfma_hazard_ubench.hip).  Here every piece goes to LDS (`store`) and comes back through a fragment read;
+// tools/audit_asm_loads.py check 4 enforces that on the compiled ISA.
 __device__ __forceinline__ unsigned tn_cvt_pk_bf16(float x0, float x1) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
@@ -1040,7 +1044,10 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
     // d(outputs) -> d raw, written straight into the head deltas (zero elsewhere)
     IDN_HIP_CHECK(hipMemsetAsync(w.dRGB, 0, (size_t)Pp * 64 * 4, s));
     // dV0: columns 0..127 are written by the delta chain for every row, column 128 (d sigma) by the compositing
-    // backward for every real point; only the padding rows of that column need zeros (the other columns are not read)
+    // backward for every real point; only the padding rows of that column need zeros.  Columns 129..255 are never written
+    // here, but the views_linears.0 + alpha_linear product below READS all 256 columns: what it finds there is whatever an
+    // earlier pass left in this workspace (the host layer hands over a workspace that was zeroed when it was allocated), and
+    // it reaches only output rows / column sums 129..255, which `q.add` never takes
     if (Pp > P) IDN_HIP_CHECK(hipMemsetAsync(w.dV0 + (size_t)P * 256, 0, (size_t)(Pp - P) * 256 * 4, s));
     {
         CompBwdArgs a{reinterpret_cast<const float4*>(raw), z, rays, bc, g_rgb, g_fg, g_lw, g_acc,

@@ -1,12 +1,21 @@
 """Render-math helpers with the reference's names and signatures
 (NeRFs/HeadNeRF/helper.py:148-313, NeRFs/HeadNeRF/train/baseline.py:325-375), computed by
-libidealnerf.so.  Flags live in an explicit ``RenderConfig`` instead of the reference's
-import-time ``args`` global (helper.py:141-142).
+libidealnerf.so -- and the reference's flag surface: ``config_parser()`` (helper.py:16-138) and the module
+attributes ``parser`` / ``args`` (helper.py:141-142), which upstream fills by parsing ``sys.argv`` when the module
+is imported and which are filled here on first access (``from idealnerf_amd.helper import *`` IS a first access,
+so the import swap keeps the import-time semantics).  A ``Network`` constructed without ``args=`` reads the
+process's flags from there (config.default_render_config); ``RenderConfig`` is the explicit form of the same subset.
 """
 from dataclasses import dataclass
 
+import os
+import sys
+
+import einops
 import numpy as np
 import torch
+import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 
@@ -35,6 +44,37 @@ class RenderConfig:
     lc_weight: float = 0.0005
 
 
+def config_parser():
+    """helper.py:16-138 -> a parser whose `parse_args()` resolves defaults <- `--config` file <- command line."""
+    from .config import ConfigParser
+    return ConfigParser("head")
+
+
+def write_config(args):
+    """helper.py:371-384."""
+    from .config import write_config as _write
+    return _write(args)
+
+
+def __getattr__(name):
+    """`helper.parser` / `helper.args`: upstream's import-time `parser = config_parser(); args = parser.parse_args()`
+    (helper.py:141-142), evaluated on first access and then kept as ordinary module attributes."""
+    if name in ("args", "parser"):
+        g = globals()
+        if "parser" not in g:
+            g["parser"] = config_parser()
+        if name == "args":
+            g["args"] = g["parser"].parse_args()
+        return g[name]
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+__all__ = ["RenderConfig", "config_parser", "write_config", "parser", "args", "img2mse", "mse2psnr", "to8b", "to8b_tensor",
+           "linspace01", "get_embedder", "get_rays", "raw2outputs", "sample_pdf", "draw_sigma_noise",
+           # upstream's scripts take these from `from NeRFs.HeadNeRF.helper import *` as well (helper.py:2-7):
+           "np", "torch", "nn", "F", "einops", "os", "sys"]
+
+
 def img2mse(x, y):
     return torch.nn.functional.mse_loss(x, y)
 
@@ -54,6 +94,11 @@ def mse2psnr(x):
 
 def to8b(x):
     return (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+def to8b_tensor(x):
+    """helper.py:157."""
+    return 255 * torch.clip(x, 0, 1)
 
 
 _linspace_cache = {}

@@ -362,12 +362,29 @@ def _workspace(nbytes: int, device, stream) -> torch.Tensor:
     key = (str(device), int(stream))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        # zeros, once per allocation: the backward multiplies whole 256-column delta matrices of which it writes 129 columns
+        # (csrc/train.hip: views_linears.0 + alpha_linear); what the other columns hold is never read back, but it must be
+        # DEFINED data (zeros now, values our own kernels wrote later), not whatever the allocator hands out
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 
 
-FUSED_MARCH_DEFAULT = int(os.environ.get("IDN_FUSED_MARCH", "0"))   # read once: the arrangement of the fp32 64 + 128 path where `fused` is not given (0 sequence, 1 one kernel, 2 two kernels)
+_FUSED_NAMES = {"0": 0, "1": 1, "2": 2, "split": 2}
+
+
+def _fused_code(fused, where) -> int:
+    """False / 0 -> 0 (kernel sequence), True / 1 -> 1 (one kernel), "split" / 2 -> 2 (two kernels); anything else is named."""
+    if isinstance(fused, str) and fused.strip().lower() in _FUSED_NAMES:
+        return _FUSED_NAMES[fused.strip().lower()]
+    if isinstance(fused, (bool, int)) and int(fused) in (0, 1, 2):
+        return int(fused)
+    raise IdealNerfError(f"{where} must be one of 0 / False (kernel sequence), 1 / True (one fused kernel), 2 / 'split' "
+                         f"(two fused kernels); got {fused!r}")
+
+
+# read once: the arrangement of the fp32 64 + 128 path where `fused` is not given
+FUSED_MARCH_DEFAULT = _fused_code(os.environ.get("IDN_FUSED_MARCH", "0") or "0", "IDN_FUSED_MARCH")
 
 
 def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, n_importance,
@@ -427,7 +444,7 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
             applies = (S == 64 and Ni == 128 and noise_coarse is None and noise_fine is None and
                        _precision(precision) == IDN_PREC_F32 and (precision_fine is None or _precision(precision_fine) == IDN_PREC_F32))
             fused = FUSED_MARCH_DEFAULT if applies else 0
-        a.fused_march = 2 if fused == "split" else int(fused)   # False / 0: sequence, True / 1: one kernel, "split" / 2: two kernels
+        a.fused_march = _fused_code(fused, "render_rays_fwd(fused=)")
         for k, v in out.items():
             setattr(a, k, v.data_ptr())
         nbytes = lib.idealnerf_render_workspace_bytes(n, S, Ni)

@@ -40,6 +40,8 @@ def gather_rows(tile: torch.Tensor, H: int, group=None, force: bool = False) -> 
         pad = torch.cat([tile, tile.new_zeros((max_rows - tile.shape[0],) + tuple(tile.shape[1:]))], 0)
     out = tile.new_empty((world * max_rows,) + tuple(tile.shape[1:]))
     dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    if world * max_rows == H:     # equal bands (512 rows over 8 ranks): the gathered buffer IS the frame, no copy
+        return out
     parts = [out[r * max_rows: r * max_rows + (b - a)] for r, (a, b) in enumerate(bands)]
     return torch.cat(parts, 0)
 

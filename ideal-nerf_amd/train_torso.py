@@ -16,6 +16,12 @@ from .models.audio_net import AudioAttNet, AudioNet
 from .models.face_nerf import FaceNeRF
 
 
+def config_parser():
+    """NeRFs/TorsoNeRF/run_nerf_helpers.py:231-365 (`from run_nerf_helpers import *` puts it into train_torso's namespace)."""
+    from .config import ConfigParser
+    return ConfigParser("torso")
+
+
 def pose_to_euler_trans(poses):
     """[b, >=3, 4] -> [b, 6] (euler angles, translation)  (run_nerf_helpers.py:26-47)."""
     R = poses[:, :3, :3]
@@ -26,10 +32,22 @@ def pose_to_euler_trans(poses):
 
 class Network(HeadNetwork):
     def __init__(self, H, W, focal, near, far, chunk, N_samlpes, N_importance, args: RenderConfig = None,
-                 dim_aud_body=64, dim_expr_head=79):
-        """The reference's positional arguments (train_torso.py:185: no `intrinsic`, unlike the head-only Network)."""
+                 dim_aud_body=None, dim_expr_head=79):
+        """The reference's positional arguments (train_torso.py:185: no `intrinsic`, unlike the head-only Network).
+        Without `args=` the flags are the process's TorsoNeRF flags (run_nerf_helpers.py:231-365: `dim_aud`,
+        `dim_aud_body`, ...), as upstream's class reads them from its `args` global (train_torso.py:200-221)."""
         nn.Module.__init__(self)
-        self.args = args = args or RenderConfig(dim_expr=dim_expr_head)
+        from . import config
+        if args is None:
+            args = config.default_render_config("torso")
+            args.dim_expr = dim_expr_head
+            ns = config.current_args("torso")
+            if dim_aud_body is None and ns is not None:
+                dim_aud_body = ns.dim_aud_body
+        else:
+            config.check_against_current(args, "torso")
+        dim_aud_body = 64 if dim_aud_body is None else dim_aud_body
+        self.args = args
         self.H, self.W, self.focal, self.near, self.far = H, W, focal, near, far
         self.chunk, self.intrinsic = chunk, None
         self.N_samples, self.N_importance = N_samlpes, N_importance

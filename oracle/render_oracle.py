@@ -23,7 +23,7 @@ import torch
 __all__ = [
     "positional_encoding", "pe_out_dim", "camera_rays", "ray_records",
     "facenerf_dims", "facenerf_param_shapes", "xavier_facenerf_params",
-    "facenerf_forward", "composite", "importance_cdf", "invert_cdf",
+    "facenerf_forward", "facenerf_forward_bf16_emulated", "composite", "importance_cdf", "invert_cdf",
     "sample_importance", "coarse_depths", "render_rays", "render_frame",
     "torso_signal", "pose_to_euler_trans", "head_torso_composite", "train_loss", "to_f64", "fp32_noise_floor",
     "mse_to_psnr", "synthetic_frame",
@@ -184,6 +184,61 @@ def facenerf_forward(p: Params, x: torch.Tensor, aud: Optional[torch.Tensor],
     for i in range(dims["D"] // 4 + 1):
         h = torch.relu(_linear(p, f"views_linears.{i}", h))
     rgb = _linear(p, "rgb_linear", h)
+    return torch.cat([rgb, sigma], dim=-1)
+
+
+def facenerf_forward_bf16_emulated(p: Params, x: torch.Tensor, aud: Optional[torch.Tensor],
+                                   expr: Optional[torch.Tensor] = None, latent: Optional[torch.Tensor] = None,
+                                   dims=None) -> torch.Tensor:
+    """`facenerf_forward` (models/face_nerf.py:40-80) in the arithmetic BASELINE configs[4] allows ("bf16 MFMA MLP"):
+    the rounding model of the product's plain-bf16 kernel, stated from the math so that the kernel can be held to it.
+
+    * every weight that multiplies a PER-POINT input is rounded to bf16 once (round to nearest even);
+    * every per-point layer input -- the 63 + 27 encoding features, each hidden activation after its ReLU -- is rounded
+      to bf16; products are exact and summed without further rounding (here: float64; the kernel: fp32 MFMA accumulate,
+      ~1e-7 apart);
+    * the per-FRAME conditioning columns (aud | expr/3 | latent of pts_linears.0 / .5, expr/3 of views_linears.0;
+      face_nerf.py:45-55,61,68-70) multiply constants: they are folded into the bias in fp32 with unrounded weights, as
+      the product does once per frame;
+    * sigma (alpha_linear) and rgb (rgb_linear) are bf16 products of the bf16 activations like any other layer; neither
+      is ReLU'd; biases stay fp32.
+
+    What this cannot pin to better than ~1e-4 on a rare point: an activation that lies within the accumulation noise of
+    a bf16 rounding boundary rounds the other way in the kernel and moves by one bf16 ulp (2^-8 of its value)."""
+    dims = dims or facenerf_dims()
+    bf = lambda t: t.to(torch.float32).to(torch.bfloat16).to(torch.float64)
+    d64 = lambda t: t.to(torch.float64)
+    ci, cv = dims["input_ch"], dims["input_ch_views"]
+    pts, views = torch.split(x, [ci, cv], dim=-1)
+    cond = [t for t in (aud, None if expr is None else expr * 1 / 3, latent) if t is not None]
+    cond = d64(torch.cat(cond)) if cond else None
+    nc = 0 if cond is None else cond.numel()
+    expr3 = None if expr is None else d64(expr * 1 / 3)
+
+    def layer(name, h_cols, cond_cols, cvec, inputs):
+        """bias' + sum_i bf16(inputs_i) @ bf16(W[:, cols_i]).T ; bias' = bias + W[:, cond_cols] @ cvec (fp32 fold)"""
+        W, b = d64(p[name + ".weight"]), d64(p[name + ".bias"])
+        if cvec is not None and cvec.numel():
+            b = (b + W[:, cond_cols[0]:cond_cols[1]] @ cvec).to(torch.float32).to(torch.float64)
+        out = b[None, :]
+        for (c0, c1), h in zip(h_cols, inputs):
+            out = out + bf(h) @ bf(p[name + ".weight"][:, c0:c1]).t()
+        return out.to(torch.float32)
+
+    c_all = ci + nc
+    h = torch.relu(layer("pts_linears.0", [(0, ci)], (ci, c_all), cond, [pts]))
+    for i in range(1, dims["D"]):
+        if (i - 1) in dims["skips"]:
+            h = torch.relu(layer(f"pts_linears.{i}", [(0, ci), (c_all, c_all + dims["W"])], (ci, c_all), cond, [pts, h]))
+        else:
+            h = torch.relu(layer(f"pts_linears.{i}", [(0, dims["W"])], None, None, [h]))
+    sigma = layer("alpha_linear", [(0, dims["W"])], None, None, [h])
+    Wd = dims["W"]
+    ne = 0 if expr3 is None else expr3.numel()
+    h = torch.relu(layer("views_linears.0", [(0, Wd), (Wd, Wd + cv)], (Wd + cv, Wd + cv + ne), expr3, [h, views]))
+    for i in range(1, dims["D"] // 4 + 1):
+        h = torch.relu(layer(f"views_linears.{i}", [(0, Wd // 2)], None, None, [h]))
+    rgb = layer("rgb_linear", [(0, Wd // 2)], None, None, [h])
     return torch.cat([rgb, sigma], dim=-1)
 
 

@@ -30,6 +30,8 @@ import oracle
 
 RGB_TOL = 1e-4
 W_TOL = 1e-5
+E2E_CAP = 1e-3          # no ray may be further than this from the oracle END TO END, sharp scene or not (measured: <= 4.4e-4)
+BEYOND_SHARE = 0.03     # ... and at most this share of the rays (or 3 rays) may be beyond 1e-4 end to end (measured: <= 2.1 %)
 
 
 def _np(a):
@@ -119,10 +121,16 @@ def check_stage(what, out, ref, n_importance, u=None):
     return w_err
 
 
-def prove(what, on_ref_positions, on_hip_positions, e2e, ref, flipped, flip_rate, flip_bound):
-    """(3) + the end-to-end statistics for one per-ray quantity.  `on_ref_positions` = (HIP fine pass on the oracle's
+def prove(what, on_ref_positions, on_hip_positions, e2e, ref, flipped, flip_rate, flip_bound, same_positions=None):
+    """(3) + the END-TO-END guards for one per-ray quantity.  `on_ref_positions` = (HIP fine pass on the oracle's
     positions, the oracle's own output on them); `on_hip_positions` = (HIP end to end, the oracle's fine pass on the HIP
-    positions); `e2e`, `ref`: the two end-to-end results."""
+    positions); `e2e`, `ref`: the two end-to-end results; `same_positions`: per ray, whether the HIP fine positions equal
+    the oracle's bit for bit (None: the reference fixture does not carry them).
+
+    End to end (so that a regression which moves pixels THROUGH the importance sampling cannot pass on the stage checks
+    alone): a ray whose fine positions are the oracle's is inside the fixed 1e-4; no ray at all is beyond `E2E_CAP`; and
+    the rays beyond 1e-4 are at most `BEYOND_SHARE` of the rays (the reference's own ill-conditioning between the passes,
+    module docstring: measured 0 .. 2.1 % by scene)."""
     scale = max(np.abs(_np(ref)).max(), 1e-30)
     ea = per_ray_err(on_ref_positions[0], on_ref_positions[1], scale)
     eh = per_ray_err(on_hip_positions[0], on_hip_positions[1], scale)
@@ -138,6 +146,12 @@ def prove(what, on_ref_positions, on_hip_positions, e2e, ref, flipped, flip_rate
     assert eh.max() < RGB_TOL, f"{what}: {eh.max():.3e} from the oracle's fine pass ON THE SAME (HIP) SAMPLE POSITIONS (ray {int(eh.argmax())})"
     assert flip_rate < flip_bound, f"{what}: index flip rate {float(flip_rate):.3e} >= {flip_bound:.1e}"
     assert getattr(flip_rate, "last", 0.0) < 0.6, f"{what}: the u = 1 draw differs on {flip_rate.last:.1%} of the rays"
+    assert ee.max() < E2E_CAP, f"{what}: end to end {ee.max():.3e} from the oracle (ray {int(ee.argmax())}; cap {E2E_CAP:.0e})"
+    assert int(bad.sum()) <= max(3, BEYOND_SHARE * len(ee)), f"{what}: {int(bad.sum())} of {len(ee)} rays beyond 1e-4 end to end"
+    if same_positions is not None:
+        same = np.asarray(same_positions, dtype=bool)
+        assert ee[same].max(initial=0.0) < RGB_TOL, (f"{what}: a ray whose fine sample positions ARE the oracle's is "
+                                                      f"{ee[same].max():.3e} from it end to end")
     return dict(on_ref_positions_max=float(ea.max()), on_hip_positions_max=float(eh.max()), e2e_max=float(ee.max()),
                 beyond=int(bad.sum()), beyond_without_flip=int(no_flip.sum()), flip_rate=float(flip_rate),
                 flip_rate_last=getattr(flip_rate, "last", 0.0))
@@ -153,4 +167,6 @@ def prove_render(idn, what, out, ref, packed_f, folded_f, rays, bc, oracle_fine,
     ora_on_hip = oracle_fine(out["tap_z_fine"])
     fl, rate = flipped_rows(out["tap_inds"], ref["tap_inds"])
     bound = small_sample_bound(flip_bound, int(np.prod(ref["tap_inds"].shape)))
-    return {k: prove(f"{what} {k}", (hip_on_ref[k], ref[k]), (out[k], ora_on_hip[k]), out[k], ref[k], fl, rate, bound) for k in keys}
+    same = (out["tap_z_fine"].cpu() == torch.as_tensor(ref["tap_z_fine"]).reshape(out["tap_z_fine"].shape)).all(1).numpy()
+    return {k: prove(f"{what} {k}", (hip_on_ref[k], ref[k]), (out[k], ora_on_hip[k]), out[k], ref[k], fl, rate, bound, same)
+            for k in keys}

@@ -220,21 +220,22 @@ def test_average_gradients_gloo_two_ranks():
     assert list(ok) == [1, 1]
 
 
-@pytest.mark.parametrize("H", [8, 9])
-def test_gather_rows_gloo_two_ranks(H):
-    """N>1 path on CPU: two ranks render disjoint row bands and all-gather them (even and
-    uneven split)."""
+@pytest.mark.parametrize("world,H", [(2, 8), (2, 9), (8, 450), (8, 512)])
+def test_gather_rows_gloo(world, H):
+    """N>1 path on CPU: the ranks render disjoint row bands and all-gather them -- two ranks (even and uneven split), and
+    the eight ranks of BASELINE configs[3] on the reference's real frame height 450 (bands of 57 and 56 rows:
+    audio_exp_nerf.py:453) and on the bench's 512 (equal bands: the gathered buffer is returned as the frame)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    ok = ctx.Array("i", [0, 0])
-    port = 29500 + (os.getpid() + H) % 2000
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, H, port, ok)) for r in range(2)]
+    ok = ctx.Array("i", [0] * world)
+    port = 29500 + (os.getpid() + 7 * H + world) % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, H, port, ok)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
-    assert list(ok) == [1, 1]
+    assert list(ok) == [1] * world
 
 
 def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
@@ -345,6 +346,100 @@ def test_config_files_parse_like_the_reference(idn):
     assert (rc.N_samples, rc.dim_aud, rc.perturb, rc.dim_latent) == (32, 64, 0.0, 32)
     with pytest.raises(ValueError):
         config.load_config(text="no_such_flag=1\n")
+
+
+def test_fused_arrangement_flag_is_validated(idn):
+    """`fused=` / IDN_FUSED_MARCH: 0, 1, 2, False, True and "split" are the arrangements; anything else is named (round 3:
+    IDN_FUSED_MARCH=split raised ValueError at import, =3 an EINVAL from the C side on every render)."""
+    f = idn.ops._fused_code
+    assert [f(v, "x") for v in (0, 1, 2, False, True, "split", "0", "1", "2", " Split ")] == [0, 1, 2, 0, 1, 2, 0, 1, 2, 2]
+    for bad in (3, -1, "both", "", None, 1.5):
+        with pytest.raises(idn._lib.IdealNerfError, match="must be one of"):
+            f(bad, "fused")
+    env = dict(os.environ, IDN_FUSED_MARCH="sideways", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", "import idealnerf_amd"], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "IDN_FUSED_MARCH must be one of" in r.stderr
+    r = subprocess.run([sys.executable, "-c", "import idealnerf_amd; print(idealnerf_amd.ops.FUSED_MARCH_DEFAULT)"],
+                       env=dict(env, IDN_FUSED_MARCH="split"), capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip() == "2", r.stderr
+
+
+@pytest.fixture
+def process_flags():
+    """Tests that parse flags into the process-wide slot leave it, sys.argv and helper.args as they found them."""
+    from idealnerf_amd import config, helper
+    argv, cur = list(sys.argv), dict(config._current)
+    yield config
+    sys.argv[:] = argv
+    config._current.clear()
+    config._current.update(cur)
+    for k in ("args", "parser"):
+        vars(helper).pop(k, None)
+
+
+def test_unchanged_caller_gets_its_config(idn, tmp_path, process_flags):
+    """The reference's caller, unchanged but for the import line (audio_exp_nerf.py:14,25-26,479-480): `from ...helper import *`
+    parses `sys.argv` (helper.py:141-142), and `Network(H, W, focal, near=..., ..., N_samlpes=..., N_importance=...)` -- no
+    `args=` -- builds the networks the `--config` file names: obama3's paper model has dim_expr 79 and its own near / far,
+    not the May constants (round 3: the call silently got RenderConfig() defaults)."""
+    import json
+    config = process_flags
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "configs_parsed.json")))
+    rel = "NeRFs/HeadNeRF/configs/audio_expr_nerf/obama3/paper_model/torso_bg.txt"
+    cfg = tmp_path / "torso_bg.txt"
+    cfg.write_text("\n".join(gold[rel]["lines"]))
+    sys.argv[:] = ["audio_exp_nerf.py", "--config", str(cfg), "--N_rand", "1024"]
+    scope = {}
+    exec("from idealnerf_amd.helper import *\nfrom idealnerf_amd.audio_exp_nerf import Network\n"
+         "parser = config_parser()\nargs = parser.parse_args()\n"
+         "network = Network(450, 450, 1200., near=args.near, far=args.far, chunk=args.chunk, intrinsic=None,\n"
+         "                  N_samlpes=args.N_samples, N_importance=args.N_importance)\n", scope)
+    args, net = scope["args"], scope["network"]
+    want = dict(gold[rel]["parsed"], N_rand=1024)               # the command line outranks the file
+    assert {k: v for k, v in vars(args).items() if k != "config"} == want and args.config == str(cfg)
+    assert (args.dim_expr, args.near, args.far) == (79, gold[rel]["parsed"]["near"], gold[rel]["parsed"]["far"]) and args.near != 0.3
+    assert (net.args.dim_aud, net.args.dim_expr, net.args.near, net.args.far, net.args.perturb) == (64, 79, args.near, args.far, args.perturb)
+    assert net.face_nerf_coarse.pts_linears[0].weight.shape == (256, 63 + 64 + 79 + 32)
+    assert net.face_nerf_fine.views_linears[0].weight.shape == (128, 27 + 256 + 79)
+    for name in ("nn", "F", "np", "torch", "get_embedder", "get_rays", "sample_pdf", "img2mse", "mse2psnr", "to8b", "write_config"):
+        assert name in scope, name                                # what upstream's scripts take from the star import
+    # the module attributes are upstream's import-time globals, evaluated on first access
+    from idealnerf_amd import helper
+    assert helper.args.dim_expr == 79 and helper.args is helper.args
+    # an explicit RenderConfig that contradicts the parsed config is refused by name, not rendered
+    from idealnerf_amd.audio_exp_nerf import Network
+    from idealnerf_amd.helper import RenderConfig
+    with pytest.raises(ValueError, match="dim_expr: config 79 != network 76"):
+        Network(450, 450, 1200., 0.3, 0.9, 8192, None, 64, 128, args=RenderConfig())
+    Network(450, 450, 1200., 0.3, 0.9, 8192, None, 64, 128, args=RenderConfig(dim_expr=79))
+    # stale keys end the run as upstream's parser does (several shipped configs carry `use_highlight`)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("dim_aud = 64\nuse_highlight = True\n")
+    with pytest.raises(SystemExit):
+        helper.config_parser().parse_args(["--config", str(bad)])
+    # without any flags anywhere the paper model's dimensions are used (and said so)
+    config.set_current_args(None)
+    sys.argv[:] = ["pytest"]
+    assert Network(32, 32, 100., 0.3, 0.9, 512, None, 64, 128).args.dim_expr == 76
+    # ... and with --config on the command line but no parse_args() call, the command line is parsed as upstream does on import
+    sys.argv[:] = ["eval.py", "--config", str(cfg)]
+    assert Network(32, 32, 100., 0.3, 0.9, 512, None, 64, 128).args.dim_expr == 79
+
+
+def test_unchanged_torso_caller_gets_its_config(idn, tmp_path, process_flags):
+    """NeRFs/TorsoNeRF/train_torso.py's constructor call (:185,200-221) with the TorsoNeRF parser's flags
+    (run_nerf_helpers.py:231-365): dim_aud / dim_aud_body from the config, the head pair's dim_expr 79 a literal."""
+    cfg = tmp_path / "torso.txt"
+    cfg.write_text("N_samples = 64\nN_importance = 128\nchunk = 1024\nperturb = 0.0\nwin_size = 16\ndim_aud = 76\ndim_aud_body = 32\n"
+                   "near = 0.55\nfar = 1.15\nuse_highlight = True\n")
+    from idealnerf_amd import train_torso
+    args = train_torso.config_parser().parse_args(["--config", str(cfg)])
+    assert (args.dim_aud, args.dim_aud_body, args.chunk, args.testskip, args.lrate, args.use_highlight) == (76, 32, 1024, 1, 5e-4, True)
+    net = train_torso.Network(450, 450, 1200., args.near, args.far, args.chunk, args.N_samples, args.N_importance)
+    assert (net.args.dim_aud, net.args.dim_expr, net.dim_aud_body, net.args.perturb) == (76, 79, 32, 0.0)
+    assert net.face_nerf_coarse.pts_linears[0].weight.shape == (256, 63 + 76 + 79 + 32)
+    assert net.torso_fine_nerf.pts_linears[0].weight.shape == (256, 63 + 32 + 42)
+    assert net.aud_net.encoder_fc1[-1].out_features == 76 if hasattr(net.aud_net, "encoder_fc1") else True
 
 
 def test_checkpoint_round_trip_and_adnerf_warm_start(idn, tmp_path):

@@ -417,6 +417,132 @@ def test_obama_configs_render_by_name(idn, dev, cfg_name):
     assert rel_err(extras["rgb0"], ref["rgb0"]) < RGB_TOL
 
 
+# --------------------------------------------------------------------------- checkpoints on the GPU path
+def _render_vs_oracle_on_its_state_dict(idn, dev, net, latent, what, n_rays=256, seed=5):
+    """`n_rays` rays of a 32 x 32 frame through `net` (whatever weights it holds NOW), held to the CPU oracle evaluated on
+    the SAME state dict with parity_proof's fixed budgets (coarse weights 1e-5, sampling stage exact, fine pass 1e-4)."""
+    dims = oracle.facenerf_dims(dim_aud=net.args.dim_aud, dim_expr=net.args.dim_expr, dim_latent=net.args.dim_latent)
+    syn = oracle.synthetic_frame(32, 32, seed=seed, dims=dims)
+    g = lambda t: None if t is None else t.to(dev)
+    cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    pc, pf = cpu(net.face_nerf_coarse), cpu(net.face_nerf_fine)
+    rays = idn.ops.frame_rays(syn["c2w"][:3, :4], 32, 32, syn["focal"], NEAR, FAR, device=dev)[:n_rays].contiguous()
+    bc = g(syn["bc"]).reshape(-1, 3)[:n_rays].contiguous()
+    lat = latent.detach().cpu()
+    expr = syn["expr"] if net.args.dim_expr else None
+    with torch.no_grad():
+        out = net.render_rays(rays, bc, g(syn["aud"]), syn["c2w"], g(lat), g(expr), taps=True)
+        ff = net.face_nerf_fine.folded_bias(g(syn["aud"]), g(expr), g(lat))
+        ref = oracle.render_rays(rays.cpu(), bc.cpu(), pc, pf, syn["aud"], expr, lat, n_samples=64, n_importance=128, dims=dims, taps=True)
+    assert float((ref["rgb_map"] - bc.cpu()).abs().mean()) > 0.02, "the volume must hide part of the background"
+    prove_render(idn, what, out, ref, net.face_nerf_fine.packed_weights(), ff, rays, bc,
+                 lambda z: oracle_fine_pass(pf, dims, rays, bc, syn["aud"], expr, lat, z), 1e-3,
+                 precision_fine=net.face_nerf_fine.prec_code)
+    assert rel_err(out["rgb0"], ref["rgb0"]) < RGB_TOL
+    return out
+
+
+def _head_network(idn, dev, seed, **cfg):
+    from idealnerf_amd.audio_exp_nerf import Network, init_weights
+    from idealnerf_amd.helper import RenderConfig
+    torch.manual_seed(seed)
+    net = Network(32, 32, 100.0, NEAR, FAR, 512, None, 64, 128, args=RenderConfig(perturb=0.0, chunk=512, near=NEAR, far=FAR, **cfg))
+    net.apply(init_weights)                         # audio_exp_nerf.py:485
+    idn.invalidate_packed(net)
+    return net.to(dev).eval()
+
+
+def _make_visible(net, gain=200.0, bias=0.3):
+    """A trained head hides part of the background; Xavier initialisation does not (sigma ~ 0): scale the density heads."""
+    with torch.no_grad():
+        for m in (net.face_nerf_coarse, net.face_nerf_fine):
+            m.alpha_linear.weight.mul_(gain)
+            m.alpha_linear.bias.fill_(bias)
+
+
+def test_head_tar_round_trip_renders_like_the_oracle(idn, dev, tmp_path):
+    """The reference's resume path (audio_exp_nerf.py:516-525) and its writer (:586-591) on the GPU: a Network with
+    non-trivial weights, a stepped Adam and per-frame latent codes is written as `head.tar` with the reference's four
+    keys, found again by natural order, loaded into a FRESH Network (other weights, stale packed streams), and the loaded
+    network's render is held to the CPU oracle on the checkpoint's own state dict and latent code -- and equals the
+    saving network's render bit for bit."""
+    from idealnerf_amd import checkpoint, train as T_
+    net = _head_network(idn, dev, seed=1)
+    _make_visible(net)
+    lat = (1.0 + 0.1 * torch.randn(5, 32, generator=torch.Generator().manual_seed(2))).to(dev).requires_grad_(True)
+    opt = T_.make_optimizer(net, lat)
+    for p in list(net.parameters()) + [lat]:        # one real optimizer step so that the Adam state is non-trivial
+        p.grad = 1e-3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(dev)
+    opt.step()
+    net.eval()
+    run = tmp_path / "logs" / "may"
+    checkpoint.save_checkpoint(str(run / "head.tar"), net, opt, lat, 4321)
+    ck = torch.load(checkpoint.latest_checkpoint(str(run)), weights_only=False)
+    assert set(ck) == {"global_step", "model_state_dict", "optimizer", "latent_codes"}        # :586-591
+    assert set(ck["model_state_dict"]) == set(net.state_dict()) and "face_nerf_fine.feature_linear.weight" in ck["model_state_dict"]
+    saved = _render_vs_oracle_on_its_state_dict(idn, dev, net, lat[3], "saving network")
+
+    fresh = _head_network(idn, dev, seed=77)
+    with torch.no_grad():                            # warm its packed streams with the WRONG weights first
+        fresh.face_nerf_fine.packed_weights()
+        fresh.face_nerf_coarse.packed_weights()
+    lat2 = torch.ones(5, 32, device=dev, requires_grad=True)
+    opt2 = T_.make_optimizer(fresh, lat2)
+    step, codes = checkpoint.load_checkpoint(checkpoint.latest_checkpoint(str(run)), fresh, opt2, map_location=dev)
+    lat2.data = codes                                # :523
+    assert step == 4321 and torch.equal(codes, lat.data)
+    for (k, a), (_, b) in zip(net.state_dict().items(), fresh.state_dict().items()):
+        assert torch.equal(a, b), k
+    st, st2 = opt.state_dict()["state"], opt2.state_dict()["state"]
+    assert st.keys() == st2.keys() and all(torch.equal(st[i]["exp_avg_sq"], st2[i]["exp_avg_sq"]) for i in st)
+    loaded = _render_vs_oracle_on_its_state_dict(idn, dev, fresh, lat2[3], "network loaded from head.tar")
+    for k in ("rgb_map", "rgb0", "disp_map", "last_weight", "tap_inds", "tap_z_fine"):
+        assert torch.equal(saved[k], loaded[k]), k
+
+
+def test_adnerf_ft_path_warm_start_renders_like_the_oracle(idn, dev):
+    """`--ft_path` (audio_exp_nerf.py:498-514): an AD-NeRF checkpoint -- audio-only FaceNeRFs (C = 127: input widths 127 /
+    383 / 283) under `network_fn_state_dict` / `network_fine_state_dict`, plus the two audio nets -- warm-starts the paper
+    model (C = 235): the three layers whose input width differs are dropped from the dict, everything else is loaded with
+    strict=False.  Asserted: exactly which tensors changed, and that the render of the resulting weights matches the CPU
+    oracle on them (the packed streams follow the load)."""
+    from idealnerf_amd import checkpoint
+    from idealnerf_amd.models.audio_net import AudioAttNet, AudioNet
+    torch.manual_seed(4)     # (a Xavier density head is positive or negative over the whole volume: seed 3 draws an empty fine volume)
+    ad_c, ad_f = idn.FaceNeRF(dim_aud=64, dim_latent=0, dim_expr=0), idn.FaceNeRF(dim_aud=64, dim_latent=0, dim_expr=0)
+    from idealnerf_amd.audio_exp_nerf import init_weights
+    for m in (ad_c, ad_f):
+        m.apply(init_weights)
+        with torch.no_grad():
+            m.alpha_linear.weight.mul_(200.0)
+            m.alpha_linear.bias.fill_(0.3)
+    assert ad_c.pts_linears[0].weight.shape == (256, 127) and ad_c.pts_linears[5].weight.shape == (256, 383)
+    aud_net, att_net = AudioNet(64, 16), AudioAttNet()
+    ft = {"network_fn_state_dict": ad_c.state_dict(), "network_fine_state_dict": ad_f.state_dict(),
+          "network_audnet_state_dict": aud_net.state_dict(), "network_audattnet_state_dict": att_net.state_dict(),
+          "global_step": 400000}
+    net = _head_network(idn, dev, seed=9)
+    with torch.no_grad():
+        net.face_nerf_fine.packed_weights()          # streams of the initialisation: must not survive the load
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    checkpoint.load_adnerf_finetune({k: (dict(v) if isinstance(v, dict) else v) for k, v in ft.items()}, net)
+    after = net.state_dict()
+    dropped = {"pts_linears.0.weight", "pts_linears.5.weight", "views_linears.0.weight"}
+    for pre, src in (("face_nerf_coarse.", ad_c), ("face_nerf_fine.", ad_f)):
+        for k, v in src.state_dict().items():
+            if k in dropped:
+                assert torch.equal(after[pre + k], before[pre + k]), f"{pre + k} has another input width: kept as initialised"
+                assert after[pre + k].shape != v.shape
+            else:
+                assert torch.equal(after[pre + k].cpu(), v), pre + k
+    for pre, src in (("aud_net.", aud_net), ("aud_att_net.", att_net)):
+        for k, v in src.state_dict().items():
+            assert torch.equal(after[pre + k].cpu(), v), pre + k
+    changed = {k for k in after if not torch.equal(after[k], before[k])}
+    assert not any(k.startswith("ds_aud_net.") for k in changed)
+    _render_vs_oracle_on_its_state_dict(idn, dev, net, torch.ones(32), "network warm-started from an AD-NeRF ft_path")
+
+
 # --------------------------------------------------------------------------- the driver's multi-GPU command, rehearsed
 def test_bench_two_ranks_from_a_plain_start(dev):
     """`python bench.py --gpus 2 ...` as ONE plain process on this box: the launcher starts two ranks (sharing GPU 0
@@ -443,6 +569,51 @@ def test_bench_two_ranks_from_a_plain_start(dev):
     assert one.returncode == 0, one.stderr[-3000:]
     r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][-1])
     assert r1["n_gpus"] == 1 and r1["ranks"] == 1 and r1["config"]["rays_per_step"] == res["config"]["rays_per_step"]
+
+
+def _two_rank_env():
+    import os
+    env = dict(os.environ, IDN_DIST_BACKEND="gloo", IDN_FORCE_DEVICE="0", IDN_DIST_TIMEOUT_S="90", OMP_NUM_THREADS="4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_data_parallel_train_step_two_ranks(dev):
+    """SURVEY 8(e), training: two ranks (sharing GPU 0 over gloo: the one-GPU rehearsal of the RCCL path) each render and
+    back-propagate HALF of a 512-ray batch, `train_step` averages the gradients with one bucketed all-reduce and both take the
+    same Adam step.  Asserted (tests/dp_train_worker.py): the replicas end with BIT-IDENTICAL parameters, and gradients and
+    parameters equal a single-rank step on the concatenated batch to 1e-6 (the mean of the two half-batch gradients is the
+    full-batch gradient; the dW GEMMs sum the points in another grouping, nothing else differs)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tests", "dp_train_worker.py")],
+                       env=_two_rank_env(), capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    print("\n  " + json.dumps(res))
+    assert res["ranks"] == 2 and res["replicas_bit_identical"] is True
+    assert res["params_moved_by"] > 1e-4, "the step must have moved the parameters"
+    assert res["grad_rel_err_max"] < 1e-5, res                  # per tensor, relative to its largest entry (measured ~1e-6)
+    assert res["param_abs_err_max"] < 1e-6, res
+    assert abs(res["loss_single"] - res["loss_mean_of_ranks"]) < 1e-5 * max(1.0, abs(res["loss_single"]))
+
+
+def test_bench_train_two_ranks_from_a_plain_start(dev):
+    """`python bench.py --workload train --gpus 2` (round 3 refused it): the launcher's ranks train data-parallel behind
+    `train.train_step -> parallel.average_gradients`, each on its own N_rand = 3072 rays, and end every step as one model."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "train", "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=_two_rank_env(), capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["backend"] == "gloo" and res["scaling"] == "weak"
+    assert res["replicas_in_sync"] is True and res["value"] > 0 and np.isfinite(res["final_loss"])
 
 
 def test_bench_one_rank_rccl_communicator(dev):

@@ -841,8 +841,9 @@ def prove_head_torso(idn, what, net, P, dims, d, dev, rgb_com, flip_bound):
     ora_on_hip = compose(oracle_fine_pass(P["hf"], dims[0], rays_h, bg, aud_feature, d["expr"], d["latent"], head["tap_z_fine"]),
                          oracle_fine_pass(P["tf"], dims[1], rays_t, bg, aud_torso, None, None, torso["tap_z_fine"], with_fg=True))
     (fl_h, rate_h), (fl_t, rate_t) = flipped_rows(head["tap_inds"], ref_h["tap_inds"]), flipped_rows(torso["tap_inds"], ref_t["tap_inds"])
+    same = ((head["tap_z_fine"].cpu() == ref_h["tap_z_fine"]).all(1) & (torso["tap_z_fine"].cpu() == ref_t["tap_z_fine"]).all(1)).numpy()
     res = prove(what, (on_ref, ref), (hip_com, ora_on_hip), hip_com, ref, fl_h | fl_t, max(rate_h, rate_t, key=float),
-                small_sample_bound(flip_bound, head["tap_inds"].numel()))
+                small_sample_bound(flip_bound, head["tap_inds"].numel()), same)
     return res, ref, ref0
 
 
@@ -901,8 +902,9 @@ def test_head_torso_golden(idn, dev, golden):
     ora_on_hip = compose(oracle_fine_pass(P["hf"], dh, rays_h, bg, aud_feature, d["expr"], d["latent"], head["tap_z_fine"]),
                          oracle_fine_pass(P["tf"], dt, rays_t, bg, aud_torso, None, None, torso["tap_z_fine"], with_fg=True))
     (fl_h, rate_h), (fl_t, rate_t) = flipped_rows(head["tap_inds"], g["inds_head"]), flipped_rows(torso["tap_inds"], g["inds_torso"])
+    same = ((zf(head, "head") == head["tap_z_fine"].cpu()).all(1) & (zf(torso, "torso") == torso["tap_z_fine"].cpu()).all(1)).numpy()
     res = prove("head+torso vs the reference's composite", (on_ref, g["rgb_com"]), (rgb_com, ora_on_hip), rgb_com, g["rgb_com"],
-                fl_h | fl_t, max(rate_h, rate_t, key=float), FLIP_TOL_SHARP)
+                fl_h | fl_t, max(rate_h, rate_t, key=float), FLIP_TOL_SHARP, same)
     assert res["beyond"] < 0.03 * 512     # a statistic of this scene (measured: 6 rays), not a criterion: the criteria are in prove()
 
 
@@ -1224,20 +1226,44 @@ def test_bf16x3_module_precision_switch(idn, dev, golden):
 
 # --------------------------------------------------------------------------- plain bf16 (config 5)
 BF16 = 2  # IDN_PREC_BF16
+BF16_MODEL_TYPICAL = 2e-5   # median point vs the rounding model (fp32 accumulation order is all that differs)
+BF16_MODEL_WORST = 1e-3     # a rare activation on a bf16 rounding boundary moves by 2^-8 of itself
 
 
-def test_bf16_facenerf_error_budget(idn, dev, golden):
-    """Plain bf16 operands, fp32 accumulate: ~1e-2 on the raw output - outside the
-    1e-4 budget by design, which is why it is only offered for the PSNR-judged config."""
+def _bf16_vs_emulation(idn, dev, params, x, aud, expr, lat, dims, what):
+    """The plain-bf16 kernel against the oracle's model of its rounding (oracle.facenerf_forward_bf16_emulated: weights and
+    per-point layer inputs rounded to bf16 once, exact products, fp32 folded biases).  Errors are relative to max |ref|.
+    The bound is what separates "the arithmetic the model states" from anything else: a hazard that feeds stale operands
+    to 2 of 16 channels (shipped in rounds 1-2 under a 3e-2 bound) moves EVERY point by ~1e-2; what the model cannot pin
+    is an activation within the accumulation noise of a bf16 rounding boundary, which then moves by one bf16 ulp
+    (2^-8 of itself) at a rare point: hence a tight bound on the typical point and a looser one on the worst."""
+    cond = [None if t is None else t.to(dev) for t in (aud, expr, lat)]
+    with torch.no_grad():
+        emu = oracle.facenerf_forward_bf16_emulated(params, x, aud, expr, lat, dims).double()
+        f32 = oracle.facenerf_forward(params, x, aud, expr, lat, dims).double()
+    sd = {k: t.to(dev).contiguous() for k, t in params.items()}
+    ps = idn.ops.params_struct(sd, dims["dim_aud"], dims["dim_expr"], dims["dim_latent"])
+    out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, BF16), idn.ops.fold_conditioning(ps, *cond, dev), x.to(dev), BF16)
+    assert out.shape == emu.shape
+    scale = float(emu.abs().max())
+    e = ((out.cpu().double() - emu).abs().max(1)[0] / scale).numpy()
+    vs32 = float((out.cpu().double() - f32).abs().max() / f32.abs().max())
+    print(f"\n  plain bf16 {what}: vs the bf16 rounding model median {np.median(e):.2e}, 99th pct {np.percentile(e, 99):.2e}, "
+          f"max {e.max():.2e} ({len(e)} points); vs fp32 (report) {vs32:.2e}")
+    return e, vs32
+
+
+def test_bf16_facenerf_follows_its_rounding_model(idn, dev, golden):
+    """Plain bf16 operands, fp32 accumulate (BASELINE configs[4]): ~6.5e-3 from the fp32 reference output by design --
+    and within ~1e-5 of what rounding weights and layer inputs to bf16 PREDICTS, on the reference's golden inputs."""
     g = golden("facenerf")
-    dims = oracle.facenerf_dims()
-    sd = {k: t.to(dev).contiguous() for k, t in oracle.xavier_facenerf_params(11, dims).items()}
-    ps = idn.ops.params_struct(sd, 64, 76, 32)
-    folded = idn.ops.fold_conditioning(ps, *(T(g["c235_" + k]).to(dev) for k in ("aud", "expr", "latent")), dev)
-    out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, BF16), folded, T(g["c235_x"]).to(dev), BF16)
-    err = rel_err(out, g["c235_out"])
-    print(f"\nplain bf16 FaceNeRF: max rel err vs reference = {err:.2e}")
-    assert 1e-4 < err < 3e-2
+    for name, v in (("c235", dict(dim_aud=64, dim_expr=76, dim_latent=32)), ("c169", dict(dim_aud=106, dim_expr=0, dim_latent=0))):
+        dims = oracle.facenerf_dims(**v)
+        params = oracle.xavier_facenerf_params(11, dims)
+        opt = lambda k: T(g[f"{name}_{k}"]) if f"{name}_{k}" in g and g[f"{name}_{k}"].size else None
+        e, vs32 = _bf16_vs_emulation(idn, dev, params, T(g[f"{name}_x"]), opt("aud"), opt("expr"), opt("latent"), dims, name)
+        assert np.median(e) < BF16_MODEL_TYPICAL and e.max() < BF16_MODEL_WORST, (name, np.median(e), e.max())
+        assert 1e-4 < vs32 < 3e-2      # it IS bf16: outside the 1e-4 budget, offered for the PSNR-judged config only
 
 
 @pytest.mark.parametrize("n", [1, 130, 4099])
@@ -1247,13 +1273,8 @@ def test_bf16_ragged(idn, dev, n):
     rs = np.random.RandomState(n)
     x = T(rs.uniform(-1, 1, size=(n, 90)).astype(np.float32))
     aud, expr, lat = (T(rs.standard_normal(k).astype(np.float32)) for k in (64, 76, 32))
-    with torch.no_grad():
-        ref = oracle.facenerf_forward(params, x, aud, expr, lat, dims)
-    sd = {k: t.to(dev).contiguous() for k, t in params.items()}
-    ps = idn.ops.params_struct(sd, 64, 76, 32)
-    out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, BF16),
-                               idn.ops.fold_conditioning(ps, aud.to(dev), expr.to(dev), lat.to(dev), dev), x.to(dev), BF16)
-    assert out.shape == ref.shape and rel_err(out, ref) < 3e-2
+    e, vs32 = _bf16_vs_emulation(idn, dev, params, x, aud, expr, lat, dims, f"ragged n={n}")
+    assert np.median(e) < BF16_MODEL_TYPICAL and e.max() < BF16_MODEL_WORST and vs32 < 3e-2
 
 
 def test_bf16_render_frame32_psnr(idn, dev, golden):
@@ -1711,6 +1732,93 @@ def test_random_scenes_fp32_and_mixed_vs_oracle(idn, dev, seed):
         assert rel_err(out["rgb0"], ref["rgb0"]) < RGB_TOL, mode   # the coarse composite has no sampling before it
 
 
+# --------------------------------------------------------------------------- empty space (most rays of a real head frame)
+# Where the volume is empty a compositing weight is alpha * T with alpha = 1 - exp(-1e-6 * dz |d|) ~ 1e-8: in fp32 that is 0 or
+# one ulp below 1 (6e-8) by the last bit of exp, whichever code evaluates it, so two correct fp32 implementations differ by up to
+# 6e-8 per bin THERE.  sample_pdf (helper.py:271-275) adds 1e-5 to each of the 62 interior weights and divides by their sum,
+# ~6.2e-4: a cdf edge e moves by up to e * 6e-8 / 6.2e-4 = e * 1e-4, and an importance index flips whenever one of the 128 draws
+# (spacing 1/127) lies between the two positions of an edge -- probability 127 * |shift|.  Summed over the 62 edges that is at
+# most 127 / 128 * 1e-4 * (1 + 2 + ... + 62) = 0.19 flipped indices per index if EVERY bin of a ray differed in the same
+# direction; what the floor implies is therefore a flip-rate bound of 0.2 for empty rays, and the measured rate (a few 1e-3:
+# the two exps agree on most arguments) is reported, not bounded more tightly.  None of it can move a pixel: every sample the
+# flips relocate sits in empty space, so end to end EVERY ray is within 1e-4 (in fact 1e-6) -- that is what is asserted.
+EMPTY_SPACE_FLIP_BOUND = 0.2
+
+
+def _empty_space_scene(idn, dev, seed, empty_share):
+    """160 rays of a 32 x 32 frame through a coarse / fine pair whose density heads are shifted so that `empty_share` of
+    the volume has sigma <= 0 (1.0: the whole volume; 0.5: the field is positive in about half of it, in the spatially
+    coherent blobs a smooth MLP draws -- every ray crosses empty stretches and most cross a dense one)."""
+    dims = oracle.facenerf_dims()
+    rs = np.random.RandomState(seed)
+    syn = oracle.synthetic_frame(32, 32, seed=seed, dims=dims)
+    rays = idn.ops.frame_rays(syn["c2w"], 32, 32, syn["focal"], NEAR, FAR, device=dev)
+    sel = torch.from_numpy(rs.choice(1024, 160, replace=False))
+    r = rays[sel.to(dev)].contiguous()
+    bc = syn["bc"].reshape(-1, 3)[sel].contiguous()
+    cond = (syn["aud"], syn["expr"], syn["latent"])
+    rc = r.cpu()
+    z = oracle.coarse_depths(rc[:, 6:7], rc[:, 7:8], 64, None)
+    pts = rc[:, None, 0:3] + rc[:, None, 3:6] * z[:, :, None]
+    nets = []
+    for s0 in (300, 400):
+        p = scale_sigma(oracle.xavier_facenerf_params(s0 + seed, dims), 200.0, 0.0)
+        with torch.no_grad():
+            sig = oracle.render_oracle._query(p, pts, rc[:, -3:], *cond, dims)[..., 3].reshape(-1)
+        if empty_share >= 1.0:
+            # (the fine pass evaluates the field between the coarse samples: leave half the field's range as margin)
+            p["alpha_linear.bias"] = torch.full_like(p["alpha_linear.bias"], -float(sig.max()) - 0.5 * float(sig.max() - sig.min()))
+        else:
+            p["alpha_linear.bias"] = torch.full_like(p["alpha_linear.bias"], -float(torch.quantile(sig, empty_share)))
+        nets.append(p)
+    pc, pf = nets
+    with torch.no_grad():
+        ref = oracle.render_rays(rc, bc, pc, pf, *cond, n_samples=64, n_importance=128, dims=dims, taps=True)
+    packs = []
+    for p in (pc, pf):
+        sd = {k: v.to(dev).contiguous() for k, v in p.items()}
+        ps = idn.ops.params_struct(sd, 64, 76, 32)
+        packs.append((idn.ops.pack_weights(ps, dev, 0), idn.ops.fold_conditioning(ps, *(c.to(dev) for c in cond), dev), sd))
+    out = idn.ops.render_rays_fwd(r, bc.to(dev), packs[0][0], packs[0][1], packs[1][0], packs[1][1],
+                                  torch.linspace(0.0, 1.0, 64).to(dev), torch.linspace(0.0, 1.0, 128).to(dev), 128, taps=True)
+    res = prove_render(idn, f"empty share {empty_share:.1f}, scene {seed}", out, ref, packs[1][0], packs[1][1], r, bc.to(dev),
+                       lambda zf: oracle_fine_pass(pf, dims, r, bc, *cond, zf), EMPTY_SPACE_FLIP_BOUND)
+    return out, ref, bc, res["rgb_map"]
+
+
+@pytest.mark.parametrize("seed", [12, 13])
+def test_empty_volume_is_the_background_on_every_ray(idn, dev, seed):
+    """sigma <= 0 everywhere (helper.py:271-275 runs on weights of ~1e-8 over its 1e-5 floor): parity_proof's three legs on
+    every ray, the frame equal to the background to 1e-6 in both passes, EVERY ray within 1e-4 of the oracle end to end --
+    and the importance-index flip rate reported against the bound the floor implies (derivation above)."""
+    out, ref, bc, res = _empty_space_scene(idn, dev, seed, 1.0)
+    assert float((ref["rgb_map"] - bc).abs().max()) < 1e-6, "the oracle's volume is not empty"
+    for k in ("rgb_map", "rgb0"):
+        assert abs_err(out[k], bc) < 1e-6, k
+    assert res["beyond"] == 0 and res["e2e_max"] < 1e-5, res
+    assert abs_err(out["acc_map"], ref["acc_map"]) < 1e-6
+    print(f"  empty volume {seed}: interior flip rate {res['flip_rate']:.2e} (bound from the 1e-5 floor: {EMPTY_SPACE_FLIP_BOUND})")
+
+
+@pytest.mark.parametrize("seed", [12, 13])
+def test_half_empty_volume_vs_oracle(idn, dev, seed):
+    """The density is positive in about half of the volume: every ray has empty stretches whose bins sit on the 1e-5 floor
+    next to bins that carry mass.  The three legs on every ray, every ray within 1e-4 end to end (the rays that cross
+    nothing are the background to 1e-6), the flip rate reported against the floor's bound."""
+    out, ref, bc, res = _empty_space_scene(idn, dev, seed, 0.5)
+    vis = (ref["rgb_map"] - bc).abs().max(1)[0]
+    assert float(vis.mean()) > 0.02, "half of the volume must carry density"
+    floor_bins = float((ref["tap_weights_coarse"][:, 1:-1] < 1e-6).float().mean())
+    assert 0.2 < floor_bins < 0.9, f"{floor_bins:.0%} of the coarse bins sit on sample_pdf's floor: not a half-empty scene"
+    empty_rays = (ref["tap_weights_fine"][:, :-1].sum(1) < 1e-6)
+    if bool(empty_rays.any()):
+        assert abs_err(out["rgb_map"][empty_rays.to(dev)], bc[empty_rays]) < 1e-6
+    assert res["beyond"] == 0, res
+    assert rel_err(out["rgb0"], ref["rgb0"]) < RGB_TOL
+    print(f"  half-empty volume {seed}: {floor_bins:.0%} of the coarse bins on the floor, {int(empty_rays.sum())} of 160 rays cross nothing; interior flip rate {res['flip_rate']:.2e} "
+          f"(bound from the 1e-5 floor: {EMPTY_SPACE_FLIP_BOUND})")
+
+
 # --------------------------------------------------------------------------- fp16x3 arithmetic mode
 FP16X3 = 3  # IDN_PREC_FP16X3
 
@@ -1832,6 +1940,38 @@ def test_bf16x6_facenerf_golden_ragged_and_range(idn, dev, golden):
     folded = idn.ops.fold_conditioning(ps, aud.to(dev), expr.to(dev), lat.to(dev), dev)
     out = idn.ops.facenerf_fwd(idn.ops.pack_weights(ps, dev, BF16X6), folded, x.to(dev), BF16X6)
     assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("dims_kw,seed,n_rays,S", [(dict(dim_aud=64, dim_expr=79, dim_latent=32), 22, 512, 192),
+                                                    (dict(dim_aud=106, dim_expr=0, dim_latent=0), 24, 517, 192),
+                                                    (dict(dim_aud=64, dim_expr=76, dim_latent=32), 3, 4096, 64)])
+def test_bf16x6_launches_are_bit_identical_and_agree_with_fp32(idn, dev, dims_kw, seed, n_rays, S):
+    """The six-piece kernels make their bf16 pieces with inline-asm conversions whose distance from the MFMA that reads
+    them (two wait states: tools/valu_mfma_hazard_ubench.hip) is a property of the code's structure, audited on the compiled
+    ISA in the CPU suite -- which a GPU box without hipcc cannot run.  This is the same guard on the device: a violated
+    hazard showed as results that differ FROM RUN TO RUN and by orders of magnitude (round 3: 1e29).  Eight launches of the
+    bf16x6 forward on every CU must be bit-identical, and fp32-grade against the fp32 MFMA kernel on the same inputs."""
+    dims = oracle.facenerf_dims(**dims_kw)
+    p = oracle.xavier_facenerf_params(seed, dims)
+    p["alpha_linear.weight"] = p["alpha_linear.weight"] * 100.0
+    sd = {k: v.to(dev).contiguous() for k, v in p.items()}
+    ps = idn.ops.params_struct(sd, dims["dim_aud"], dims["dim_expr"], dims["dim_latent"])
+    rs = np.random.RandomState(1)
+    cond = [None if not d else T(rs.standard_normal(d).astype(np.float32)).to(dev) for d in (dims["dim_aud"], dims["dim_expr"], dims["dim_latent"])]
+    folded = idn.ops.fold_conditioning(ps, *cond, dev)
+    syn = oracle.synthetic_frame(64, 64, seed=4)
+    rays = idn.ops.frame_rays(syn["c2w"], 64, 64, syn["focal"], NEAR, FAR, device=dev)[:n_rays].contiguous()
+    z = idn.ops.coarse_depths(rays, torch.linspace(0, 1, S).to(dev))
+    pk6, pk32 = idn.ops.pack_weights(ps, dev, BF16X6_CODE), idn.ops.pack_weights(ps, dev, 0)
+    ref = idn.ops.query_rays_fwd(pk32, folded, rays, z, 0)
+    outs = [idn.ops.query_rays_fwd(pk6, folded, rays, z, BF16X6_CODE).clone() for _ in range(8)]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0]).all())
+    for i, o in enumerate(outs[1:], 1):
+        assert torch.equal(o, outs[0]), f"launch {i} differs from launch 0"
+    e = rel_err(outs[0], ref)
+    print(f"\n  bf16x6 vs fp32 kernel, {n_rays} rays x {S}: {e:.2e}")
+    assert e < 1e-5
 
 
 def test_bf16x6_render_frame32_golden(idn, dev, golden):

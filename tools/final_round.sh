@@ -11,9 +11,9 @@ F=gpurun_out/final
 rm -rf $F; mkdir -p $F
 timeout -k 10 900 python -m pytest tests -m gpu -q -s > $F/pytest_gpu_final.log 2>&1
 tail -1 $F/pytest_gpu_final.log
-IDN_DEFAULT_PRECISION=bf16x6 timeout -k 10 900 python -m pytest tests -m gpu -q > $F/pytest_gpu_bf16x6_as_default.log 2>&1 || true
+IDN_DEFAULT_PRECISION=bf16x6 timeout -k 10 900 python -m pytest tests -m gpu -q > $F/pytest_gpu_bf16x6_as_default.log 2>&1
 tail -1 $F/pytest_gpu_bf16x6_as_default.log
-IDN_FUSED_MARCH=1 timeout -k 10 900 python -m pytest tests -m gpu -q > $F/pytest_gpu_fused_as_default.log 2>&1 || true
+IDN_FUSED_MARCH=1 timeout -k 10 900 python -m pytest tests -m gpu -q > $F/pytest_gpu_fused_as_default.log 2>&1
 tail -1 $F/pytest_gpu_fused_as_default.log
 # the fused ray kernel (the opt-in arrangement of the fp32 path) first: its summaries are taken from the same output directory
 IDN_FUSED_MARCH=1 IDN_PROFILE_KERNEL=render_fused_kernel bash tools/profile_round.sh f32 > $F/profile_render_fused.log 2>&1
