@@ -308,13 +308,14 @@ def train_measurement(dev, steps, warmup, world=1, rank=0, backend=None):
     import types
     import torch.distributed as dist
     args = types.SimpleNamespace(steps=steps, warmup=warmup)
-    torch.manual_seed(rank)   # perturb=1 draws the stratified offsets from torch's generator: same run, same loss
+    torch.manual_seed(0)      # the audio nets' initialisation: the SAME model on every rank
     H = W = 450
     syn = synthetic.frame(H, W, seed=0)
     cfg = RenderConfig(perturb=1.0, chunk=8192, near=syn["near"], far=syn["far"])
     net = Network(H, W, syn["focal"], syn["near"], syn["far"], 8192, None, 64, 128, args=cfg).to(dev).train()
     synthetic.xavier_state_dict(net.face_nerf_coarse, 2, 300.0, 0.3)
     synthetic.xavier_state_dict(net.face_nerf_fine, 3, 300.0, 0.3)
+    torch.manual_seed(rank)   # perturb=1 draws the stratified offsets from torch's generator: same run, same loss; each rank its own draws
     rs = np.random.RandomState(rank)     # every rank samples its own rays of the frame; the weights above are the same everywhere
     uni = rs.choice(H * W, 2432, replace=False)
     yy, xx = np.meshgrid(np.arange(250, 310), np.arange(175, 275), indexing="ij")

@@ -125,14 +125,19 @@ __device__ unsigned long long g_tn_diag[8];   // total, wait (vmcnt + barrier), 
 #define TN_STAMP(v)
 #endif
 
-template <int NTW, int KTW>
+// NB = LDS buffers of the chunk ring: the pieces of chunk c + NB - 1 are issued while chunk c is multiplied.  The 256 x 256
+// shape (32 KiB per chunk, 16 MFMAs per point pair and wave) runs NB = 3; the narrow shapes do a quarter of the arithmetic per
+// byte (a 256 x 64 chunk is 20 KiB for 4 MFMAs per point pair: 1 us of matrix time, less than a loaded HBM round trip) and
+// run a deeper ring, so that several chunks per workgroup are in flight.
+template <int NTW, int KTW, int NB = kTnBufs>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
+    static_assert(NB >= 3 && (NB - 2) * (NTW + KTW) <= 63, "vmcnt is a 6-bit field");
     constexpr int BN = 64 * NTW, BK = 64 * KTW;
     constexpr int kTileFloats = kTnRows * (BN + BK);       // one chunk: A tile then B tile
     constexpr int kSteps = kTnRows / 2;                    // point-pairs per chunk
     constexpr int NP = NTW + KTW;                          // 1-KiB pieces per wave and chunk (<= kSteps)
     static_assert(NP <= kSteps, "at most one piece per step");
-    extern __shared__ __attribute__((aligned(16))) float tn_smem[];  // kTnBufs * kTileFloats
+    extern __shared__ __attribute__((aligned(16))) float tn_smem[];  // NB * kTileFloats
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hh = lane >> 5;
@@ -195,16 +200,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)tn_smem;
     const uint32_t a_addr0 = smem0 + (hh * BN + NTW * (32 * wr + i)) * 4;
     const uint32_t b_addr0 = smem0 + (kTnRows * BN + hh * BK + KTW * (32 * wc + i)) * 4;
-    for (int j = 0; j < NP; ++j)
-        if (c_begin < c_end) piece(c_begin, 0, j);
-    for (int j = 0; j < NP; ++j)
-        if (c_begin + 1 < c_end) piece(c_begin + 1, 1, j);
+    // every chunk's NP pieces are issued even past the end of the split (clamped to its last chunk: re-read, never used), so
+    // that exactly (NB - 2) * NP younger vector-memory operations are in flight at every chunk's wait
+    for (int ahead = 0; ahead < NB - 1; ++ahead)
+        for (int j = 0; j < NP; ++j) piece(c_begin + ahead < c_end ? c_begin + ahead : c_end - 1, ahead, j);
     int buf = 0;
     for (long c = c_begin; c < c_end; ++c) {
         TN_STAMP(dg_a);
-        // this wave's pieces of chunk c have landed (those of chunk c + 1, issued later, may still be in flight)
-        if (c + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's pieces of chunk c have landed (those of chunks c + 1 .. c + NB - 2, issued later, may still be in flight)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * NP) : "memory");
         // everyone's have; everyone is done with chunk c - 1, whose buffer chunk c + 2 now takes.  A raw barrier:
         // __syncthreads() would add its own vmcnt(0) and wait for the pieces of chunk c + 1 as well
         __builtin_amdgcn_s_barrier();
@@ -213,8 +217,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 #ifdef IDN_DIAG
         dg_wait += dg_b - dg_a;
 #endif
-        const int buf2 = buf >= 1 ? buf - 1 : kTnBufs - 1;   // (buf + 2) % 3
-        const bool more = c + 2 < c_end;
+        const int buf2 = buf >= 1 ? buf - 1 : NB - 1;   // (buf + NB - 1) % NB: the buffer chunk c - 1 has just left
+        const long cnext = c + NB - 1 < c_end ? c + NB - 1 : c_end - 1;   // clamped: the re-read of the last chunk is never used
+        constexpr bool more = true;
         // The delta tile is in LDS anyway: its column sums are the bias gradient.  The kTnRows reads of column
         // `tid` go out first (inline asm, like the operand reads) and are added after the first counted wait of
         // the loop below, which covers them (LDS returns in order): read by plain loads they parked every wave
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
         for (int it = 0; it < kSteps / 4; ++it) {
             a1v.template issue<kStepA>(pa);
             b1v.template issue<kStepB>(pb);
-            if (more && 2 * it < NTW) piece_a(c + 2, buf2, 2 * it);
+            if (more && 2 * it < NTW) piece_a(cnext, buf2, 2 * it);
             lds_retire<2>(a0v, b0v);
             if (colsum_block && it == 0) {   // the column reads were issued before a0v / b0v: they have landed too
                 tn_static_for<kTnRows>([&](auto R) { csum += landed(cs[decltype(R)::value]); });
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
             pb += 2 * kStepB;
             a0v.template issue<0>(pa);
             b0v.template issue<0>(pb);
-            if (more && 2 * it + 1 < NTW) piece_a(c + 2, buf2, 2 * it + 1);
+            if (more && 2 * it + 1 < NTW) piece_a(cnext, buf2, 2 * it + 1);
             lds_retire<2>(a1v, b1v);
             mm(a1v, b1v);
         }
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
         for (int it = 0; it < kSteps / 4; ++it) {
             a1v.template issue<kStepA>(pa);
             b1v.template issue<kStepB>(pb);
-            if (more && 2 * it < KTW) piece_b(c + 2, buf2, 2 * it);
+            if (more && 2 * it < KTW) piece_b(cnext, buf2, 2 * it);
             lds_retire<2>(a0v, b0v);
             mm(a0v, b0v);
             // the pair after next; past the last pair the read is repeated on the current rows (never used):
@@ -278,18 +283,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
             pb = last ? pb : pb + 2 * kStepB;
             a0v.template issue<0>(pa);
             b0v.template issue<0>(pb);
-            if (more && 2 * it + 1 < KTW) piece_b(c + 2, buf2, 2 * it + 1);
+            if (more && 2 * it + 1 < KTW) piece_b(cnext, buf2, 2 * it + 1);
             lds_retire<2>(a1v, b1v);
             mm(a1v, b1v);
         }
         lds_retire<0>(a0v, b0v);   // drain the repeated read before these registers are reused
-        buf = buf + 1 == kTnBufs ? 0 : buf + 1;
+        buf = buf + 1 == NB ? 0 : buf + 1;
         TN_STAMP(dg_a);
 #ifdef IDN_DIAG
         dg_loop += dg_a - dg_b;
 #endif
     }
     TN_STAMP(dg_t1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-reads of the last chunk: nothing may land in LDS after this workgroup has left
     if (do_colsum) g.cpart[(long)split * g.N + n0 + tid] = csum;
     // this lane holds, for tile (x, y) register r: output (n0 + NTW (32 wr + d_row(r, hh)) + x, k0 + KTW (32 wc + i) + y):
     // the KTW values of one (x, r) are contiguous in a row of the partial block
@@ -378,12 +384,11 @@ __device__ __forceinline__ void x6_retire(X6Frag (&f)[3]) {
 }
 
 // One 256 x 256 product (one split of the points) of the batch below.
-__device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, char* x6_smem) {
+__device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split, char* x6_smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hh = lane >> 5;
     const int wr = w >> 1, wc = w & 1;
-    const int split = blockIdx.z;
     f32x16 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -577,19 +582,21 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, char* x6_smem) 
             for (int r = 0; r < 16; ++r)
                 out[(long)(32 * (4 * wr + x) + d_row(r, hh)) * g.K + 32 * (4 * wc + y) + i] = acc[x][y][r];
 }
-// The 256 x 256 weight-gradient products of a pass as ONE launch: every workgroup (= one split of the points) walks the
-// items in turn.  They were nine dependent launches per pass (each ~0.2 ms, with a dispatch gap and a ramp between them);
-// inside one kernel an item's 256 KB of partial sums drain while the next item's first chunks are already loading.  Every
-// wave has passed the last chunk barrier of an item before anything of the next one is written to LDS.
+// The 256 x 256 weight-gradient products of a pass as ONE launch, ONE PRODUCT PER WORKGROUP: workgroup z works on item
+// z / splits over split z % splits of the points, with splits = 2 #CUs / #items (56 for the nine products of a pass on 256 CUs).
+// Round 3 walked all items in every workgroup (256 splits each): 9 x 256 partial blocks of 256 KB per pass -- 590 MB written
+// and read back by the reduction, whatever the number of points (17 % of the coarse pass's traffic).  Now a workgroup keeps
+// its accumulators over 1 / 56 of the points and writes ONE block: 131 MB per pass, and the reduction reads less than a quarter.
 constexpr int kMaxTnBatch = 12;
 struct TNBatch {
     TNArgs it[kMaxTnBatch];
-    int n;
+    int n, splits;
 };
 __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(TNBatch b) {
     extern __shared__ __attribute__((aligned(16))) char x6_smem[];
-#pragma unroll 1
-    for (int l = 0; l < b.n; ++l) gemm_tn_x6_item(b.it[l], x6_smem);
+    const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.z / b.splits);
+    const int split = __builtin_amdgcn_readfirstlane((int)blockIdx.z - item * b.splits);
+    gemm_tn_x6_item(b.it[item], split, x6_smem);
 }
 
 // out[n*ldo + k] = sum_s part[s][n][k],  n < rows, k < cols  (rows/cols may be smaller than N/K: padding dropped)
@@ -823,9 +830,18 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kMaxSplits = 256;
 constexpr int kColsumBlocks = 256;   // rows of the column-sum partial buffer (>= kMaxSplits)
 constexpr int kGemmsPerPass = 16;
+constexpr int kX6ItemsPerPass = 9;   // pts_linears.1..7, views_linears.0 + alpha_linear, the views_linears.1 / .2 pair
 // partial-slab floats of one split over all GEMMs of a pass: 9 of 256x256 (pts_linears.1..7, views_linears.0 + alpha_linear, the
 // views_linears.1 / .2 pair), 2 of 256x64, 1 of 128x64, 1 of 64x128 -- with room for the fp32 pipe's two 128x128
-constexpr size_t kPartFloatsPerSplit = 9 * 65536 + 4 * 16384 + 2 * 8192;   // (the fp32 pipe: 8 + 2 x 16384 for the views pair)
+constexpr size_t kPartFloatsPerSplit = 9 * 65536 + 6 * 16384 + 4 * 8192;   // (the fp32 pipe: 8 + 2 x 16384 for the views pair; the narrow shapes may run 2 x kMaxSplits splits)
+// The narrow shapes (256 x 64, 128 x 64, 64 x 128 outputs: pts_linears.0, the encoding columns of pts_linears.5, the direction
+// columns of views_linears.0, rgb_linear) are HBM-shaped: ring depth and workgroups per CU decide how many bytes they keep in flight
+#ifndef IDN_TN_NARROW_BUFS
+#define IDN_TN_NARROW_BUFS 6
+#endif
+#ifndef IDN_TN_NARROW_SPLITS
+#define IDN_TN_NARROW_SPLITS 256
+#endif
 
 struct BwdWs {
     float *dA[8], *dV[2], *dV0, *dRGB, *part, *cpart, *wbwd;
@@ -875,6 +891,7 @@ static int default_gemm_pipe() { return (IDN_DW_X6 && !env_pipe_f32()) ? kPipeX6
 struct X6Pending {
     TNBatch b;
     int splits = 0;
+    int expected_items = 1;   // how many products the caller will queue: the CUs are divided among them (run_tn_partials)
     X6Pending() { b.n = 0; }
     int launch(hipStream_t s) {
         if (b.n == 0) return IDN_OK;
@@ -887,7 +904,8 @@ struct X6Pending {
             return e;
         {
             ProfScope prof(s, b.it[0].P * b.n, IDN_PROF_DW_GEMM_X6);
-            hipLaunchKernelGGL(gemm_tn_x6_kernel, dim3(1, 1, splits), dim3(256), kX6Lds, s, b);
+            b.splits = splits;
+            hipLaunchKernelGGL(gemm_tn_x6_kernel, dim3(1, 1, splits * b.n), dim3(256), kX6Lds, s, b);
         }
         IDN_HIP_CHECK(hipGetLastError());
         b.n = 0;
@@ -901,6 +919,26 @@ struct X6Pending {
         return IDN_OK;
     }
 };
+static int device_cus(int* out) {
+    static LaunchSetup st;
+    return st.get([]() -> int { return IDN_OK; }, out);
+}
+template <int NTW, int KTW, int NB>
+static int launch_tn(const TNArgs& g, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)NB * kTnRows * (size_t)(64 * NTW + 64 * KTW) * 4;
+    static_assert(lds <= 160 * 1024, "the chunk ring must fit a CU's LDS");
+    static LaunchSetup setup;
+    int num_cu = 0;
+    if (int e = setup.get([]() -> int {
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<NTW, KTW, NB>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            return IDN_OK;
+        }, &num_cu))
+        return e;
+    hipLaunchKernelGGL((gemm_tn_kernel<NTW, KTW, NB>), grid, dim3(256), lds, s, g);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
 static int run_tn_partials(X6Pending& x6, const float* A, int lda, int N, const float* B, int ldb, int K, int64_t P, float* part,
                            int* splits_out, hipStream_t s, float* cpart = nullptr, int pipe = -1, const float* B2 = nullptr) {
     if (pipe < 0) pipe = default_gemm_pipe();
@@ -916,7 +954,16 @@ static int run_tn_partials(X6Pending& x6, const float* A, int lda, int N, const 
     else return fail(IDN_EUNSUPPORTED, "gemm_tn: no instantiation for %d x %d", N, K);
     const int bx = N / (64 * ntw), by = K / (64 * ktw);
     const long chunks = P / kTnRows;
-    int splits = kMaxSplits / (bx * by);
+    const bool narrow = ntw * ktw <= 4 && !(ntw == 2 && ktw == 2);     // <4,1>, <2,1>, <1,2>
+    int splits = (narrow ? IDN_TN_NARROW_SPLITS : kMaxSplits) / (bx * by);
+    if (ntw == 4 && ktw == 4 && pipe == kPipeX6) {   // one product per workgroup: the CUs are divided among the pass's products
+        int cus = 0;
+        if (int e = device_cus(&cus)) return e;
+        // two rounds of workgroups per CU: the tail is still balanced (2 x 28 x 9 = 504 workgroups on 256 CUs), the fp32 accumulators
+        // run over 1 / 56 of the points (10 500 of the fine pass's 589 824) and the partial blocks are 131 MB per pass
+        splits = 2 * cus / (x6.expected_items > 0 ? x6.expected_items : 1);
+        if (splits > kMaxSplits) splits = kMaxSplits;
+    }
     if (splits > chunks) splits = (int)chunks;
     if (splits < 1) splits = 1;
     const int cps = (int)((chunks + splits - 1) / splits);
@@ -931,33 +978,21 @@ static int run_tn_partials(X6Pending& x6, const float* A, int lda, int N, const 
         g.b_off0 = (int)o0;
         g.b_off1 = (int)o1;
     }
-    const dim3 grid(bx, by, splits), block(256);
-    const size_t lds = (size_t)kTnBufs * kTnRows * (size_t)(64 * ntw + 64 * ktw) * 4;
-    static LaunchSetup setup;
-    int num_cu = 0;
-    if (int e = setup.get([]() -> int {
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<4, 4>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kTnBufs * kTnRows * 512 * 4));
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<4, 1>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kTnBufs * kTnRows * 320 * 4));
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<2, 4>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kTnBufs * kTnRows * 384 * 4));
-            return IDN_OK;
-        }, &num_cu))
-        return e;
+    const dim3 grid(bx, by, splits);
     if (ntw == 4 && ktw == 4 && pipe == kPipeX6) {   // queued: launched with the pass's other 256 x 256 products (ReduceQueue::flush)
         if (int e = x6.add(g, splits, s)) return e;
         *splits_out = splits;
         return IDN_OK;
     }
     ProfScope prof(s, P, IDN_PROF_DW_GEMM);
-    if (ntw == 4 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, lds, s, g);
-    else if (ntw == 4 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), grid, block, lds, s, g);
-    else if (ntw == 2 && ktw == 4) hipLaunchKernelGGL((gemm_tn_kernel<2, 4>), grid, block, lds, s, g);
-    else if (ntw == 2 && ktw == 1) hipLaunchKernelGGL((gemm_tn_kernel<2, 1>), grid, block, lds, s, g);
-    else if (ntw == 2 && ktw == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, lds, s, g);
-    else hipLaunchKernelGGL((gemm_tn_kernel<1, 2>), grid, block, lds, s, g);
-    IDN_HIP_CHECK(hipGetLastError());
+    int e;
+    if (ntw == 4 && ktw == 4) e = launch_tn<4, 4, kTnBufs>(g, grid, s);
+    else if (ntw == 4 && ktw == 1) e = launch_tn<4, 1, IDN_TN_NARROW_BUFS>(g, grid, s);
+    else if (ntw == 2 && ktw == 4) e = launch_tn<2, 4, kTnBufs>(g, grid, s);
+    else if (ntw == 2 && ktw == 1) e = launch_tn<2, 1, IDN_TN_NARROW_BUFS>(g, grid, s);
+    else if (ntw == 2 && ktw == 2) e = launch_tn<2, 2, kTnBufs>(g, grid, s);
+    else e = launch_tn<1, 2, IDN_TN_NARROW_BUFS>(g, grid, s);
+    if (e) return e;
     *splits_out = splits;
     return IDN_OK;
 }
@@ -968,7 +1003,10 @@ struct ReduceQueue {
     float* part_next;    // slab pools of the workspace
     float* cpart_next;
     X6Pending x6;        // the 256 x 256 bf16-piece products queued so far: one launch, in front of the reductions
-    ReduceQueue(float* part_pool, float* cpart_pool) : part_next(part_pool), cpart_next(cpart_pool) { b.n = 0; }
+    ReduceQueue(float* part_pool, float* cpart_pool, int expected_x6_items = 1) : part_next(part_pool), cpart_next(cpart_pool) {
+        b.n = 0;
+        x6.expected_items = expected_x6_items;
+    }
     // out[(0..rows) x (0..cols)] (ld ldo) = sum over splits of the N x K partial blocks, from row row0 / column col0 on
     int add(const float* part, int splits, int N, int K, int row0, int col0, float* out, int ldo, int rows, int cols) {
         if (b.n >= kMaxReduceItems) return fail(IDN_EUNSUPPORTED, "reduce queue full");
@@ -1017,11 +1055,13 @@ int launch_dw_gemm(const float* delta, int ld_delta, const float* acts, int ld_a
                    void* ws, size_t ws_bytes, hipStream_t s) {
     if (rows <= 0 || rows % 128) return fail(IDN_EINVAL, "dw_gemm: rows %lld is not a positive multiple of 128", (long long)rows);
     if (ld_delta < 256 || ld_acts < 256) return fail(IDN_EINVAL, "dw_gemm: row pitch < 256");
+    const int as_in_a_pass = pipe == 2;   // IDN_DW_PIPE_BF16X6_PASS: the split count a pass runs its nine products with
+    if (as_in_a_pass) pipe = kPipeX6;
     if (pipe != kPipeX6 && pipe != kPipeF32) return fail(IDN_EINVAL, "dw_gemm: pipe %d", pipe);
     if (!ws || ws_bytes < dw_gemm_workspace_bytes()) return fail(IDN_EWORKSPACE, "dw_gemm workspace %zu < %zu", ws_bytes, dw_gemm_workspace_bytes());
     float* part = reinterpret_cast<float*>(ws);
     float* cpart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + al256((size_t)kMaxSplits * 65536 * 4));
-    ReduceQueue q(part, cpart);
+    ReduceQueue q(part, cpart, as_in_a_pass ? kX6ItemsPerPass : 1);
     if (int e = run_tn(q, delta, ld_delta, 256, acts, ld_acts, 256, rows, dW, 256, 256, 256, s, db, db ? 256 : 0, pipe)) return e;
     return q.flush(s);
 }
@@ -1072,7 +1112,7 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
         TRY(launch_delta_chain(w.wbwd, acts, Pp, w.dRGB, w.dV0, w.dV[0], w.dV[1], w.dA, s));
     }
     // weight and bias gradients: dW_l = delta_l^T a_{l-1} (contraction over the points), db_l = column sums
-    ReduceQueue q(w.part, w.cpart);
+    ReduceQueue q(w.part, w.cpart, kX6ItemsPerPass);
     TRY(run_tn(q, w.dRGB, 64, 64, v_l(3), 128, 128, Pp, gr.rgb_w, 128, 3, 128, s, gr.rgb_b, 3));
     // views_linears.2 and .1 (128 x 128 each): on the bf16 pipe ONE 256 x 256 launch whose A is the side-by-side delta matrix and
     // whose B columns come from the two activation matrices (v2 | v1) -- the weight gradients are its diagonal blocks, and 1 KB per

@@ -16,7 +16,10 @@ from .._lib import IDN_PREC_BF16, IDN_PREC_BF16X3, IDN_PREC_BF16X6, IDN_PREC_F32
 
 PRECISIONS = {"f32": IDN_PREC_F32, "bf16x3": IDN_PREC_BF16X3, "bf16": IDN_PREC_BF16, "fp16x3": IDN_PREC_FP16X3,
               "bf16x6": IDN_PREC_BF16X6}
-_default_precision = [os.environ.get("IDN_DEFAULT_PRECISION", "f32")]   # modules created from here on (set_default_precision)
+# The arithmetic of modules created without further ado (DESIGN.md section 9 states the criterion, tests/parity_proof.py:
+# default_precision_criterion holds the shipped choice to it); IDN_DEFAULT_PRECISION / set_default_precision override it.
+SHIPPED_DEFAULT_PRECISION = "f32"
+_default_precision = [os.environ.get("IDN_DEFAULT_PRECISION", SHIPPED_DEFAULT_PRECISION)]   # modules created from here on
 
 
 def set_render_precision(network, mode: str):

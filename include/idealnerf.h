@@ -318,6 +318,8 @@ int idealnerf_pass_bwd(const idn_facenerf_params* p, const idn_facenerf_grads* g
  */
 #define IDN_DW_PIPE_BF16X6 0
 #define IDN_DW_PIPE_F32 1
+#define IDN_DW_PIPE_BF16X6_PASS 2   /* BF16X6 with the split count of a training pass (2 #CUs / 9 workgroups: each keeps its fp32
+                                       accumulators over 1/56 of the rows on a 256-CU part), not one split per CU */
 size_t idealnerf_dw_gemm_workspace_bytes(void);
 int idealnerf_dw_gemm(const float* delta, int ld_delta, const float* acts, int ld_acts, int64_t rows, float* dW, float* db,
                       int pipe, void* workspace, size_t workspace_bytes, void* stream);

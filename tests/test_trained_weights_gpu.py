@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import oracle
-from parity_proof import oracle_fine_pass, prove_render
+from parity_proof import assert_default_precision_allowed, default_precision_criterion, oracle_fine_pass, prove_render
 
 pytestmark = pytest.mark.gpu
 
@@ -141,3 +141,4 @@ def test_trained_weights_parity_all_modes(dev=None):
         assert m[mode]["vs_fp64"]["rgb_max_rel"] < 1.5 * ref64["rgb_max_rel"] + 2e-5, mode
         assert m[mode]["vs_fp64"]["index_flip_rate"] < 1.5 * ref64["index_flip_rate"] + 1e-4, mode
     assert m["fp16x3"]["psnr_db"] > 100.0 and m["bf16x3"]["psnr_db"] > 80.0 and m["bf16"]["psnr_db"] > 40.0
+    assert_default_precision_allowed(default_precision_criterion("trained weights", proofs["f32"], proofs["bf16x6"], n), "the trained-weights scene")
