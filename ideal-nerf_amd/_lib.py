@@ -46,6 +46,11 @@ class RenderArgs(C.Structure):
                 ("lindisp", C.c_int), ("white_bkgd", C.c_int), ("noise_coarse", fp), ("noise_fine", fp), ("fused_march", C.c_int)]
 
 
+class Frame(C.Structure):
+    _fields_ = [("c2w", C.c_float * 12), ("H", C.c_int), ("W", C.c_int), ("focal", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("near_", C.c_float), ("far_", C.c_float), ("row0", C.c_int), ("nrows", C.c_int), ("rays_out", fp)]
+
+
 ABI_VERSION = 3   # idealnerf_version(): 3 since idn_render_args carries `fused_march`
 
 # name -> (restype, argtypes); mirrors include/idealnerf.h one to one
@@ -71,6 +76,8 @@ PROTOTYPES = {
     "idealnerf_invert_cdf": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp]),
     "idealnerf_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "idealnerf_render_rays_fwd": (C.c_int, [C.POINTER(RenderArgs), fp]),
+    "idealnerf_render_frame_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "idealnerf_render_frame_fwd": (C.c_int, [C.POINTER(RenderArgs), C.POINTER(Frame), fp]),
     "idealnerf_train_acts_floats": (C.c_size_t, [C.c_int64]),
     "idealnerf_query_rays_train_fwd": (C.c_int, [fp, fp, C.c_int, fp, fp, C.c_int64, C.c_int, fp, fp, fp]),
     "idealnerf_pass_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),

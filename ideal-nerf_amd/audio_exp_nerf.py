@@ -108,10 +108,15 @@ class Network(nn.Module):
         return self._batchify(rays, bc_rgb, aud_para, latent_code, expr, self.face_nerf_coarse, self.face_nerf_fine,
                               False, chunk)
 
-    def _batchify(self, rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg, chunk):
+    def _batchify(self, rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg, chunk, frame=None):
         training = torch.is_grad_enabled() and self.training
         if not training and self.args.perturb == 0.:
-            return self._render(rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg)
+            # `frame`: a full frame's row band with the rays still to be derived -- on the device, inside the one C call
+            return self._render(rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg, frame=frame)
+        if frame is not None:   # the chunk loop slices ray records: materialise them (perturb > 0 draws per chunk)
+            rays = ops.frame_rays(torch.tensor(list(frame.c2w)).reshape(3, 4), frame.H, frame.W, frame.focal, frame.near_, frame.far_,
+                                  frame.row0, frame.nrows, None if frame.cx < 0 else frame.cx, None if frame.cy < 0 else frame.cy,
+                                  device=bc_rgb.device)
         all_ret = {}
         for i in range(0, rays.shape[0], chunk):
             ret = self._render(rays[i:i + chunk], bc_rgb[i:i + chunk], aud_para, latent_code, expr, coarse, fine, with_fg)
@@ -127,7 +132,7 @@ class Network(nn.Module):
                             False, retraw, lindisp, perturb, white_bkgd, raw_noise_std, pytest, taps)
 
     def _render(self, rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg, retraw=False, lindisp=False,
-                perturb=None, white_bkgd=False, raw_noise_std=0., pytest=False, taps=False):
+                perturb=None, white_bkgd=False, raw_noise_std=0., pytest=False, taps=False, frame=None):
         """Shared body of render_rays for the head pair and the torso pair of networks
         (``with_fg`` adds the torso variant's rgb_map_fg / rgb_map_fg0 / last_weight0,
         NeRFs/TorsoNeRF/train_torso.py:326-345)."""
@@ -140,9 +145,12 @@ class Network(nn.Module):
             from .autograd import render_rays_apply
             return render_rays_apply(self, coarse, fine, rays, bc_rgb, aud_para, latent_code, expr, perturb, pytest,
                                      with_fg, lindisp=lindisp)
-        rays = rays.to(torch.float32).contiguous()
         bc_rgb = bc_rgb.to(torch.float32).contiguous()
-        n, dev = rays.shape[0], rays.device
+        if frame is None:
+            rays = rays.to(torch.float32).contiguous()
+            n, dev = rays.shape[0], rays.device
+        else:
+            n, dev = frame.nrows * frame.W, bc_rgb.device
         S, Ni = args.N_samples, args.N_importance
         t_rand, u = self.draw_randoms(n, S, Ni, perturb, pytest, dev)
         from .helper import draw_sigma_noise
@@ -159,7 +167,7 @@ class Network(nn.Module):
                                       fine.packed_weights() if Ni > 0 else None, ff,
                                       linspace01(S, dev), u, Ni, t_rand=t_rand, with_fg=with_fg, taps=taps or retraw,
                                       precision=coarse.prec_code, precision_fine=fine.prec_code if Ni > 0 else None,
-                                      lindisp=lindisp, white_bkgd=white_bkgd, noise_coarse=noise_c, noise_fine=noise_f)
+                                      lindisp=lindisp, white_bkgd=white_bkgd, noise_coarse=noise_c, noise_fine=noise_f, frame=frame)
         ret = {'rgb_map': out['rgb_map'], 'disp_map': out['disp_map'], 'acc_map': out['acc_map']}
         if with_fg:
             ret['rgb_map_fg'] = out['rgb_fg']
@@ -226,10 +234,14 @@ class Network(nn.Module):
             raise NotImplementedError("ndc=True / use_viewdirs=False are dead in the reference (SURVEY 8 a1)")
         dev = self.face_nerf_coarse.alpha_linear.weight.device
         if render_poses is not None:
+            # get_rays + the [o, d, near, far, viewdir] records (:396-427) happen on the device inside the render call
+            # (idealnerf_render_frame_fwd): the camera travels as 12 floats, no [H W, 11] tensor exists
             row0, nrows = (0, H) if rows is None else (rows[0], rows[1] - rows[0])
-            rec = ops.frame_rays(render_poses.detach().cpu(), H, W, focal, near, far, row0, nrows, device=dev)
+            frame = ops.make_frame(render_poses.detach().cpu(), H, W, focal, near, far, row0, nrows)
             bc = bc_rgb[row0:row0 + nrows].reshape(-1, 3)
             sh = (nrows, W, 3)
+            all_ret = self._batchify(None, bc, aud_para, latent_code, expr, self.face_nerf_coarse, self.face_nerf_fine, False, chunk,
+                                     frame=frame)
         else:
             rays_o, rays_d = rays
             sh = rays_d.shape
@@ -238,8 +250,7 @@ class Network(nn.Module):
             viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
             rec = torch.cat([rays_o, rays_d, near * torch.ones_like(rays_d[..., :1]),
                              far * torch.ones_like(rays_d[..., :1]), viewdirs], -1)
-            bc = bc_rgb
-        all_ret = self.batchify_rays(rec, bc, aud_para, poses=poses, latent_code=latent_code, expr=expr, chunk=chunk)
+            all_ret = self.batchify_rays(rec, bc_rgb, aud_para, poses=poses, latent_code=latent_code, expr=expr, chunk=chunk)
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
         k_extract = ['rgb_map', 'disp_map', 'acc_map', 'last_weight']

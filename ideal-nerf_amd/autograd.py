@@ -102,6 +102,9 @@ class RenderRaysFn(torch.autograd.Function):
             comp_c = smp = ops.march_fwd(raw_c, z_c, rays, bc, u, Ni, with_fg=with_fg)
         else:
             comp_c = ops.composite_fwd(raw_c, z_c, rays, bc, with_fg=with_fg, with_weights=False)
+        # outputs the loss does not touch (acc_map, last_weight, ... in the reference's loop) come back as None, not as
+        # zero tensors autograd would have to allocate and fill (a fill launch each): the C backward takes NULL for them
+        ctx.set_materialize_grads(False)
         ctx.nets, ctx.Ni, ctx.with_fg = (coarse, fine), Ni, with_fg
         ctx.cond = (aud_d, expr_d, lat_d)
         ctx.needs = (aud is not None and aud.requires_grad, latent is not None and latent.requires_grad)

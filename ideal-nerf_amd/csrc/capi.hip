@@ -349,7 +349,26 @@ size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_imp
     return carve(nullptr, n_rays, n_samples, n_importance).bytes;
 }
 
-int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
+static int render_impl(const idn_render_args* a, const idn_frame* frame, void* stream_);
+int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) { return render_impl(a, nullptr, stream_); }
+
+static size_t frame_scratch_bytes(int64_t n_rays) {
+    const int64_t c = n_rays < kRenderChunk ? n_rays : kRenderChunk;
+    return align256((size_t)c * IDN_RAY_FLOATS * sizeof(float));
+}
+size_t idealnerf_render_frame_workspace_bytes(int64_t n_rays, int n_samples, int n_importance) {
+    const size_t base = idealnerf_render_workspace_bytes(n_rays, n_samples, n_importance);
+    return base ? base + frame_scratch_bytes(n_rays) : 0;
+}
+int idealnerf_render_frame_fwd(const idn_render_args* a, const idn_frame* f, void* stream_) {
+    if (!a || !f) return fail(IDN_EINVAL, "args / frame is NULL");
+    if (a->rays) return fail(IDN_EINVAL, "frame mode derives the rays from the camera: args->rays must be NULL");
+    if (f->H <= 0 || f->W <= 0 || f->row0 < 0 || f->nrows < 0 || f->row0 + f->nrows > f->H) return fail(IDN_EINVAL, "bad frame / rows");
+    if (a->n_rays != (int64_t)f->nrows * f->W) return fail(IDN_EINVAL, "n_rays %lld != nrows * W = %lld", (long long)a->n_rays, (long long)f->nrows * f->W);
+    return render_impl(a, f, stream_);
+}
+
+static int render_impl(const idn_render_args* a, const idn_frame* frame, void* stream_) {
     if (!a) return fail(IDN_EINVAL, "args is NULL");
     if (int e = check_precision(a->precision)) return e;
     const int prec_fine = a->precision_fine_plus1 ? a->precision_fine_plus1 - 1 : a->precision;
@@ -358,13 +377,15 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
     const int S = a->n_samples, Ni = a->n_importance, Sf = S + Ni;
     if (n < 0 || S < 2 || Ni < 0) return fail(IDN_EINVAL, "bad sizes n=%lld S=%d Ni=%d", (long long)n, S, Ni);
     if (n == 0) return IDN_OK;
-    if (!a->rays || !a->bc_rgb || !a->t_vals || !a->packed_coarse || !a->folded_coarse)
+    if ((!a->rays && !frame) || !a->bc_rgb || !a->t_vals || !a->packed_coarse || !a->folded_coarse)
         return fail(IDN_EINVAL, "NULL input pointer");
     if (Ni > 0 && (!a->packed_fine || !a->folded_fine || !a->u)) return fail(IDN_EINVAL, "fine pass inputs are NULL");
     if (Ni > 0 && S < 3) return fail(IDN_EUNSUPPORTED, "importance sampling needs n_samples >= 3");
-    const size_t need = idealnerf_render_workspace_bytes(n, S, Ni);
+    const size_t need_base = idealnerf_render_workspace_bytes(n, S, Ni);
+    const size_t need = need_base + (frame ? frame_scratch_bytes(n) : 0);
     if (!a->workspace || a->workspace_bytes < need)
         return fail(IDN_EWORKSPACE, "workspace %zu bytes < required %zu", a->workspace_bytes, need);
+    float* const ray_scratch = frame ? reinterpret_cast<float*>(reinterpret_cast<char*>(a->workspace) + need_base) : nullptr;
     if (a->fused_march != 0 && a->fused_march != 1 && a->fused_march != 2) return fail(IDN_EINVAL, "fused_march %d (0 = kernel sequence, 1 = one kernel, 2 = two kernels)", a->fused_march);
     if (a->fused_march) {
         if (a->precision != IDN_PREC_F32 || prec_fine != IDN_PREC_F32) return fail(IDN_EUNSUPPORTED, "fused march: built for the fp32 arithmetic");
@@ -383,7 +404,15 @@ int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream_) {
 
     for (int64_t r0 = 0; r0 < n; r0 += kRenderChunk) {
         const int64_t c = (n - r0 < kRenderChunk) ? n - r0 : kRenderChunk;
-        const float* rays = a->rays + r0 * IDN_RAY_FLOATS;
+        const float* rays = frame ? ray_scratch : a->rays + r0 * IDN_RAY_FLOATS;
+        if (frame) {   // this pass's records: pixels [row0 W + r0, .. + c) of the frame, into the scratch the pass before has finished with
+            if (int e = launch_frame_rays_pixels(frame->c2w, frame->H, frame->W, frame->focal, frame->cx, frame->cy, frame->near_, frame->far_,
+                                                 (int64_t)frame->row0 * frame->W + r0, (int)c, ray_scratch, st))
+                return e;
+            if (frame->rays_out)
+                IDN_HIP_CHECK(hipMemcpyAsync(frame->rays_out + r0 * IDN_RAY_FLOATS, ray_scratch, (size_t)c * IDN_RAY_FLOATS * sizeof(float),
+                                             hipMemcpyDeviceToDevice, st));
+        }
         const float* bc = a->bc_rgb + r0 * 3;
         if (int e = launch_coarse_depths(rays, a->t_vals, off(a->t_rand, r0 * S), c, S, a->lindisp, w.z_c, st)) return e;
         if (!a->fused_march)

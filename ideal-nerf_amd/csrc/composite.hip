@@ -15,11 +15,12 @@ namespace idn {
 struct C2W {
     float m[12];
 };
-__global__ void frame_rays_kernel(C2W c, int W, float focal, float cx, float cy, float near_, float far_, int row0,
+__global__ void frame_rays_kernel(C2W c, int W, float focal, float cx, float cy, float near_, float far_, long pix0,
                                   int npix, float* out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix) return;
-    const int row = row0 + idx / W, col = idx % W;
+    const long pix = pix0 + idx;      // row-major pixel index in the frame
+    const int row = (int)(pix / W), col = (int)(pix % W);
     const float i = (float)col, j = (float)row;
     const float d0 = (i - cx) / focal;
     const float d1 = -(j - cy) / focal;
@@ -50,7 +51,20 @@ int launch_frame_rays(const float* c2w_host, int H, int W, float focal, float cx
     if (cy < 0) cy = H * 0.5f;
     const int npix = nrows * W;
     hipLaunchKernelGGL(frame_rays_kernel, dim3((npix + 255) / 256), dim3(256), 0, s, c, W, focal, cx, cy, near_, far_,
-                       row0, npix, rays_out);
+                       (long)row0 * W, npix, rays_out);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+// the records of the pixels [pix0, pix0 + npix) of the frame (row-major), for the frame mode of the render call
+int launch_frame_rays_pixels(const float* c2w_host, int H, int W, float focal, float cx, float cy, float near_, float far_,
+                             int64_t pix0, int npix, float* rays_out, hipStream_t s) {
+    C2W c;
+    for (int i = 0; i < 12; ++i) c.m[i] = c2w_host[i];
+    if (cx < 0) cx = W * 0.5f;
+    if (cy < 0) cy = H * 0.5f;
+    if (npix <= 0) return IDN_OK;
+    hipLaunchKernelGGL(frame_rays_kernel, dim3((npix + 255) / 256), dim3(256), 0, s, c, W, focal, cx, cy, near_, far_,
+                       (long)pix0, npix, rays_out);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }

@@ -18,7 +18,7 @@ PRECISIONS = {"f32": IDN_PREC_F32, "bf16x3": IDN_PREC_BF16X3, "bf16": IDN_PREC_B
               "bf16x6": IDN_PREC_BF16X6}
 # The arithmetic of modules created without further ado (DESIGN.md section 9 states the criterion, tests/parity_proof.py:
 # default_precision_criterion holds the shipped choice to it); IDN_DEFAULT_PRECISION / set_default_precision override it.
-SHIPPED_DEFAULT_PRECISION = "f32"
+SHIPPED_DEFAULT_PRECISION = "bf16x6"
 _default_precision = [os.environ.get("IDN_DEFAULT_PRECISION", SHIPPED_DEFAULT_PRECISION)]   # modules created from here on
 
 
@@ -83,7 +83,7 @@ class FaceNeRF(nn.Module):
         self.feature_linear = nn.Linear(W, W)  # present for checkpoint compatibility; never applied upstream
         self.alpha_linear = nn.Linear(W, 1)
         self.rgb_linear = nn.Linear(W // 2, 3)
-        self.precision = _default_precision[0]   # inference arithmetic; training always runs fp32
+        self.precision = _default_precision[0]   # inference arithmetic; training always runs an fp32-grade one (autograd.py)
         self._packed = {}
         self._packed_key = {}
 

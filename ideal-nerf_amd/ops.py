@@ -387,9 +387,25 @@ def _fused_code(fused, where) -> int:
 FUSED_MARCH_DEFAULT = _fused_code(os.environ.get("IDN_FUSED_MARCH", "0") or "0", "IDN_FUSED_MARCH")
 
 
+def make_frame(c2w, H, W, focal, near, far, row0=0, nrows=None, cx=None, cy=None):
+    """The camera of a full-frame render (idn_frame): rays of rows [row0, row0 + nrows) are derived on the device."""
+    nrows = H - row0 if nrows is None else nrows
+    if not (0 <= row0 and 0 <= nrows and row0 + nrows <= H and W > 0):
+        raise IdealNerfError(f"rows [{row0}, {row0 + nrows}) are outside a {H}x{W} frame")
+    if c2w.dim() != 2 or tuple(c2w.shape[-2:]) not in ((3, 4), (4, 4)):
+        raise IdealNerfError(f"c2w must be [3, 4] or [4, 4], got {list(c2w.shape)}")
+    f = _lib.Frame()
+    f.c2w = (C.c_float * 12)(*[float(v) for v in c2w[:3, :4].reshape(-1).tolist()])
+    f.H, f.W, f.focal = int(H), int(W), float(focal)
+    f.cx, f.cy = -1.0 if cx is None else float(cx), -1.0 if cy is None else float(cy)
+    f.near_, f.far_, f.row0, f.nrows = float(near), float(far), int(row0), int(nrows)
+    f.rays_out = None
+    return f
+
+
 def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, n_importance,
                     t_rand=None, with_fg=False, taps=False, precision=IDN_PREC_F32, precision_fine=None, lindisp=False,
-                    white_bkgd=False, noise_coarse=None, noise_fine=None, fused=None) -> Dict[str, torch.Tensor]:
+                    white_bkgd=False, noise_coarse=None, noise_fine=None, fused=None, frame=None) -> Dict[str, torch.Tensor]:
     """Network.render_rays forward (audio_exp_nerf.py:297-371) as one C call.  `precision_fine` (default: the
     same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it.
     `fused`: the arrangement of the kernels (same results bit for bit).  False / 0: the kernel sequence
@@ -398,11 +414,19 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
     re-fetches a network's 2.4 MB weight stream into every L2 at each change of network).  "split" / 2: the same kernel as
     two launches (coarse network + march | fine network + compositing): half the sequence's bytes, 0.5 % slower.  1 and 2 are
     built for fp32, 64 + 128 samples, no density noise -- anything else raises.  None: IDN_FUSED_MARCH (0 / 1 / 2, read once)
-    wherever the fused kernel applies, else the sequence."""
+    wherever the fused kernel applies, else the sequence.
+    `frame` (ops.make_frame) with `rays=None`: full-frame mode (idealnerf_render_frame_fwd) -- the ray records of the frame's
+    row band are derived on the device pass by pass; with `taps` they come back as `tap_rays`."""
     lib = _lib.load()
-    _shape(rays, "rays", None, RAY_FLOATS)
     _shape(t_vals, "t_vals", None)
-    n, S, Ni = rays.shape[0], t_vals.shape[0], int(n_importance)
+    if frame is not None:
+        if rays is not None:
+            raise IdealNerfError("frame mode derives the rays from the camera: pass rays=None")
+        n = frame.nrows * frame.W
+    else:
+        _shape(rays, "rays", None, RAY_FLOATS)
+        n = rays.shape[0]
+    S, Ni = t_vals.shape[0], int(n_importance)
     _shape(bc_rgb, "bc_rgb", n, 3)
     _shape(t_rand, "t_rand", n, S)
     _shape(noise_coarse, "noise_coarse", n, S)
@@ -413,7 +437,7 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
             raise IdealNerfError("n_importance > 0 needs u and the fine network's packed / folded buffers")
         _u_shape(u, n, Ni)
         _net_buffers(lib, packed_f, folded_f, precision if precision_fine is None else precision_fine, "_fine")
-    dev = rays.device
+    dev = bc_rgb.device
     with _Launch(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, t_rand, noise_coarse, noise_fine) as L:
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         out = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n))
@@ -447,8 +471,19 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
         a.fused_march = _fused_code(fused, "render_rays_fwd(fused=)")
         for k, v in out.items():
             setattr(a, k, v.data_ptr())
-        nbytes = lib.idealnerf_render_workspace_bytes(n, S, Ni)
-        ws = _workspace(nbytes, dev, L.stream or 0)
-        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        check(lib.idealnerf_render_rays_fwd(C.byref(a), L.stream))
+        if frame is None:
+            nbytes = lib.idealnerf_render_workspace_bytes(n, S, Ni)
+            ws = _workspace(nbytes, dev, L.stream or 0)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            check(lib.idealnerf_render_rays_fwd(C.byref(a), L.stream))
+        else:
+            tap_rays = new(n, RAY_FLOATS) if taps else None
+            frame.rays_out = None if tap_rays is None else tap_rays.data_ptr()
+            nbytes = lib.idealnerf_render_frame_workspace_bytes(n, S, Ni)
+            ws = _workspace(nbytes, dev, L.stream or 0)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            check(lib.idealnerf_render_frame_fwd(C.byref(a), C.byref(frame), L.stream))
+            frame.rays_out = None
+            if tap_rays is not None:
+                out["tap_rays"] = tap_rays
     return out

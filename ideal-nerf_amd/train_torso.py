@@ -100,9 +100,10 @@ class Network(HeadNetwork):
         from . import ops
         dev = self.face_nerf_coarse.alpha_linear.weight.device
         coarse, fine = network_nerf['coarse'], network_nerf['fine']
-        if render_poses is not None:
+        frame = None
+        if render_poses is not None:   # full frame: the rays are derived on the device inside the render call
             row0, nrows = (0, H) if rows is None else (rows[0], rows[1] - rows[0])
-            rec = ops.frame_rays(render_poses.detach().cpu(), H, W, focal, near, far, row0, nrows, device=dev)
+            frame, rec = ops.make_frame(render_poses.detach().cpu(), H, W, focal, near, far, row0, nrows), None
             bc = bc_rgb[row0:row0 + nrows].reshape(-1, 3)
             sh = (nrows, W, 3)
         else:
@@ -113,7 +114,7 @@ class Network(HeadNetwork):
             rec = torch.cat([rays_o, rays_d, near * torch.ones_like(rays_d[..., :1]),
                              far * torch.ones_like(rays_d[..., :1]), viewdirs], -1)
             bc = bc_rgb
-        all_ret = self._batchify(rec, bc, aud_para, latent_code, expr, coarse, fine, True, chunk)
+        all_ret = self._batchify(rec, bc, aud_para, latent_code, expr, coarse, fine, True, chunk, frame=frame)
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
         k_extract = ['rgb_map', 'disp_map', 'acc_map', 'last_weight', 'rgb_map_fg']

@@ -261,6 +261,27 @@ typedef struct idn_render_args {
 size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream);
 
+/*
+ * Full-frame mode: Network.render_dynamic_face with `render_poses` (audio_exp_nerf.py:396-427) -- get_rays
+ * (NeRFs/HeadNeRF/helper.py:228-243; the principal point defaults to W/2, H/2 as at :402), the viewing directions and the
+ * [o, d, near, far, viewdir] records (:407-427) followed by batchify_rays / render_rays -- as ONE call: the rays of the pixels
+ * [row0 * W, (row0 + nrows) * W) are derived on the device from the camera, one internal pass (32 768 rays) at a time into a
+ * 1.4 MB scratch that stays L2-resident; no [H * W, 11] ray tensor exists and nothing is scattered to a rank but its
+ * (row0, nrows).  `a->rays` must be NULL, `a->n_rays` = nrows * W, `a->bc_rgb` the band's background pixels; everything else as
+ * idealnerf_render_rays_fwd (same kernels: the records are the ones idealnerf_frame_rays writes, bit for bit).
+ * `rays_out` (may be NULL): [n_rays, 11] copy of the records (debug tap).
+ */
+typedef struct idn_frame {
+    float c2w[12];        /* row-major [3][4] camera-to-world */
+    int H, W;
+    float focal, cx, cy;  /* cx, cy < 0: W/2, H/2 */
+    float near_, far_;
+    int row0, nrows;
+    float* rays_out;
+} idn_frame;
+size_t idealnerf_render_frame_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
+int idealnerf_render_frame_fwd(const idn_render_args* a, const idn_frame* frame, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training step (NeRFs/HeadNeRF/train/audio_exp_nerf.py:534-552).  The forward of a pass is
  * idealnerf_coarse_depths / _query_rays_train_fwd / _composite_fwd / _sample_pdf_fwd; the

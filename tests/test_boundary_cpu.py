@@ -48,17 +48,19 @@ def test_ctypes_structs_match_c_layout(idn, tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "idealnerf.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(idn_facenerf_params), '
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(idn_facenerf_params), '
         'sizeof(idn_composite_out), sizeof(idn_render_args), offsetof(idn_facenerf_params, dim_aud), '
         'offsetof(idn_render_args, t_vals), offsetof(idn_render_args, tap_inds), '
-        'offsetof(idn_render_args, workspace_bytes), offsetof(idn_render_args, precision_fine_plus1));return 0;}\n')
+        'offsetof(idn_render_args, workspace_bytes), offsetof(idn_render_args, precision_fine_plus1), '
+        'sizeof(idn_frame), offsetof(idn_frame, focal), offsetof(idn_frame, rays_out));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     L = idn._lib
     want = [C.sizeof(L.FaceNerfParams), C.sizeof(L.CompositeOut), C.sizeof(L.RenderArgs),
             L.FaceNerfParams.dim_aud.offset, L.RenderArgs.t_vals.offset, L.RenderArgs.tap_inds.offset,
-            L.RenderArgs.workspace_bytes.offset, L.RenderArgs.precision_fine_plus1.offset]
+            L.RenderArgs.workspace_bytes.offset, L.RenderArgs.precision_fine_plus1.offset,
+            C.sizeof(L.Frame), L.Frame.focal.offset, L.Frame.rays_out.offset]
     assert got == want
 
 
@@ -73,6 +75,20 @@ def test_c_abi_argument_errors_without_gpu(idn):
     a.precision = 7
     assert lib.idealnerf_render_rays_fwd(C.byref(a), None) == -2  # IDN_EUNSUPPORTED
     assert lib.idealnerf_render_workspace_bytes(0, 64, 128) == 0
+    # frame mode: the camera replaces the ray records -- a rays pointer, rows outside the frame or a ray count that is not
+    # the band's are refused before any HIP call
+    f = idn._lib.Frame()
+    f.H, f.W, f.row0, f.nrows = 32, 32, 8, 4
+    a = idn._lib.RenderArgs()
+    a.n_rays = 4 * 32
+    a.rays = 1
+    assert lib.idealnerf_render_frame_fwd(C.byref(a), C.byref(f), None) == -1 and b"must be NULL" in lib.idealnerf_last_error()
+    a.rays = None
+    a.n_rays = 5 * 32
+    assert lib.idealnerf_render_frame_fwd(C.byref(a), C.byref(f), None) == -1 and b"nrows * W" in lib.idealnerf_last_error()
+    f.nrows = 30
+    assert lib.idealnerf_render_frame_fwd(C.byref(a), C.byref(f), None) == -1 and b"bad frame" in lib.idealnerf_last_error()
+    assert lib.idealnerf_render_frame_workspace_bytes(1000, 64, 128) == lib.idealnerf_render_workspace_bytes(1000, 64, 128) + 1000 * 44 // 256 * 256 + 256
     per_ray = lib.idealnerf_render_workspace_bytes(1000, 64, 128) / 1000
     assert 5000 < per_ray < 5500  # 5*S + 5*(S+Ni) floats per ray (z and raw of both passes), rounded up per buffer
     assert lib.idealnerf_render_workspace_bytes(10 ** 6, 64, 128) == lib.idealnerf_render_workspace_bytes(32768, 64, 128)

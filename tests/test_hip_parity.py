@@ -179,6 +179,38 @@ def test_frame_rays_golden(idn, dev, golden):
     assert torch.equal(band, rays.reshape(32, 32, 11)[8:13].reshape(-1, 11))
 
 
+@pytest.mark.parametrize("H,W,rows", [(32, 32, None), (80, 450, None), (200, 200, (20, 200)), (512, 512, (64, 192))])
+def test_frame_mode_render_equals_the_ray_record_path(idn, dev, golden, H, W, rows):
+    """`idealnerf_render_frame_fwd` takes (c2w, row band, H, W, focal, near, far) instead of a materialised
+    rays[n, 11] (helper.py:228-243, audio_exp_nerf.py:396-427 happen on the device, one internal pass at a time).  Every output
+    and every tap equals the ray-record call's BIT FOR BIT -- also where an internal 32 768-ray pass ends in the middle of a
+    row (W = 450: the reference's frame width) and for a rank's row band -- and the records themselves are the reference's
+    (frame32.npz)."""
+    dims, pc, pf, (pk_c, fold_c), (pk_f, fold_f) = _nets(idn, dev)
+    syn = oracle.synthetic_frame(H, W, seed=0, dims=dims)
+    cond = (syn["aud"], syn["expr"], syn["latent"])
+    r0, r1 = rows or (0, H)
+    rays = idn.ops.frame_rays(syn["c2w"], H, W, syn["focal"], NEAR, FAR, row0=r0, nrows=r1 - r0, device=dev)
+    bc = syn["bc"][r0:r1].reshape(-1, 3).contiguous().to(dev)
+    t, u = torch.linspace(0.0, 1.0, 64).to(dev), torch.linspace(0.0, 1.0, 128).to(dev)
+    fc, ff = fold_c(*cond), fold_f(*cond)
+    taps = (H * W <= 40000)     # (the debug taps of the 512 x 512 band would be 0.4 GB)
+    a = idn.ops.render_rays_fwd(rays, bc, pk_c, fc, pk_f, ff, t, u, 128, taps=taps)
+    frame = idn.ops.make_frame(syn["c2w"], H, W, syn["focal"], NEAR, FAR, r0, r1 - r0)
+    b = idn.ops.render_rays_fwd(None, bc, pk_c, fc, pk_f, ff, t, u, 128, taps=taps, frame=frame)
+    assert rays.shape[0] > 32768 or H == 32      # (all but the golden frame span more than one internal pass)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    if taps:
+        assert torch.equal(b["tap_rays"], rays)
+    if H == 32:
+        assert rel_err(b["tap_rays"], golden("frame32")["rays"]) < 1e-6
+    with pytest.raises(idn._lib.IdealNerfError):
+        idn.ops.render_rays_fwd(rays, bc, pk_c, fc, pk_f, ff, t, u, 128, frame=frame)       # both a camera and records
+    with pytest.raises(idn._lib.IdealNerfError):
+        idn.ops.render_rays_fwd(None, bc[:-1].contiguous(), pk_c, fc, pk_f, ff, t, u, 128, frame=frame)   # background of another band
+
+
 def test_coarse_depths_bit_exact(idn, dev, golden):
     g = golden("rays64_jitter")
     f = golden("frame32")
