@@ -620,10 +620,11 @@ def main():
         # per frame: pose -> rays, conditioning -> biases, then the per-ray path, then the tile exchange
         if i is not None:
             marks[i][0].record()
-        rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0, device=dev)
+        # (frame mode: the rays of this rank's row band are derived on the device inside the render call, pass by pass)
+        frame = ops.make_frame(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0)
         fc = coarse.folded_bias(aud, expr, latent)
         ff = fine.folded_bias(aud, expr, latent)
-        out = ops.render_rays_fwd(rays, bc, pk_c, fc, pk_f, ff, t_vals, u, Ni, precision=prec, precision_fine=prec_f)
+        out = ops.render_rays_fwd(None, bc, pk_c, fc, pk_f, ff, t_vals, u, Ni, precision=prec, precision_fine=prec_f, frame=frame)
         tile = out["rgb_map"].reshape(r1 - r0, W, 3)
         if i is not None:
             marks[i][1].record()
@@ -734,9 +735,9 @@ def main():
                 pko_c, pko_f = coarse.packed_weights(), fine.packed_weights()
                 code_c, code_f = coarse.prec_code, fine.prec_code
                 def step_other():
-                    rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0, device=dev)
-                    return ops.render_rays_fwd(rays, bc, pko_c, coarse.folded_bias(aud, expr, latent), pko_f,
-                                               fine.folded_bias(aud, expr, latent), t_vals, u, Ni, precision=code_c, precision_fine=code_f)
+                    frame = ops.make_frame(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0)
+                    return ops.render_rays_fwd(None, bc, pko_c, coarse.folded_bias(aud, expr, latent), pko_f,
+                                               fine.folded_bias(aud, expr, latent), t_vals, u, Ni, precision=code_c, precision_fine=code_f, frame=frame)
                 with torch.no_grad():
                     step_other()
                     torch.cuda.synchronize()
@@ -765,9 +766,9 @@ def main():
                     if arr == fused_headline:
                         continue
                     def step_alt():
-                        rays = ops.frame_rays(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0, device=dev)
-                        return ops.render_rays_fwd(rays, bc, pk_c, coarse.folded_bias(aud, expr, latent), pk_f, fine.folded_bias(aud, expr, latent),
-                                                   t_vals, u, Ni, precision=prec, precision_fine=prec_f, fused=arr)
+                        frame = ops.make_frame(syn["c2w"], H, W, syn["focal"], syn["near"], syn["far"], r0, r1 - r0)
+                        return ops.render_rays_fwd(None, bc, pk_c, coarse.folded_bias(aud, expr, latent), pk_f, fine.folded_bias(aud, expr, latent),
+                                                   t_vals, u, Ni, precision=prec, precision_fine=prec_f, fused=arr, frame=frame)
                     with torch.no_grad():
                         step_alt()
                         torch.cuda.synchronize()
