@@ -40,10 +40,6 @@ struct TNArgs {
     // gemm_tn_x6_kernel only: B as TWO 128-column matrices (row pitch ldb each), columns 0..127 at B + b_off0 bytes and
     // columns 128..255 at B + b_off1 bytes -- two 128 x 128 products as the diagonal blocks of one 256 x 256 launch
     int b_split, b_off0, b_off1;
-    // 1: split s works on chunks s, s + splits, s + 2 splits, ... instead of a contiguous range: at any moment the workgroups
-    // of a launch then read ONE moving window of the matrices (a few MB) instead of #splits streams that sit megabytes apart
-    int interleave;
-    int n_splits;              // gemm_tn_x6_kernel: the splits of this product (its grid carries splits x products)
     // (skipping the MFMAs of the unwanted tiles -- the off-diagonal blocks of a paired launch, rows 129..255 of views_linears.0 +
     //  alpha_linear -- behind wave-uniform branches was tried: the accumulators then flow through phis, hipcc copies registers whose
     //  asm loads are in flight (556 sites in tools/audit_asm_loads.py, results no longer reproducible) and the kernel ran 1.6x slower)
@@ -158,13 +154,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     unsigned long long dg_t0 = 0, dg_a = 0, dg_b = 0, dg_wait = 0, dg_loop = 0, dg_t1 = 0, dg_t2 = 0;
     (void)dg_t0; (void)dg_a; (void)dg_b; (void)dg_wait; (void)dg_loop; (void)dg_t1; (void)dg_t2;
     TN_STAMP(dg_t0);
-    // this split's chunks, as local indices [c_begin, c_end) = [0, n); chunk c sits `crows` rows behind chunk c - 1
+    const long c_begin = (long)split * g.chunks_per_split;
+    long c_end = c_begin + g.chunks_per_split;
     const long c_total = g.P / kTnRows;
-    const long first = g.interleave ? (long)split : (long)split * g.chunks_per_split;
-    const long crows = g.interleave ? (long)gridDim.z * kTnRows : (long)kTnRows;
-    const long c_begin = 0;
-    long c_end = g.interleave ? (c_total - first + gridDim.z - 1) / gridDim.z : (long)g.chunks_per_split;
-    if (!g.interleave && first + c_end > c_total) c_end = c_total - first;
+    if (c_end > c_total) c_end = c_total;
     const bool colsum_block = g.cpart != nullptr && blockIdx.y == 0;   // block-uniform
     const bool do_colsum = colsum_block && tid < BN;
     const int ccol = tid < BN ? tid : 0;                                  // threads beyond the tile re-read column 0 (unused)
@@ -175,8 +168,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     constexpr int kRowsPerPieceA = 256 / BN > 0 ? 256 / BN : 1, kRowsPerPieceB = 256 / BK > 0 ? 256 / BK : 1;
     // descriptors based at this block's first row: the 32-bit piece offsets then span one split (tens of MB), not the
     // whole matrix (which passes 4 GB from 4 M points on)
-    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + n0 + first * kTnRows * (long)g.lda), 0, 0xfffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + k0 + first * kTnRows * (long)g.ldb), 0, 0xfffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + n0 + c_begin * kTnRows * (long)g.lda), 0, 0xfffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + k0 + c_begin * kTnRows * (long)g.ldb), 0, 0xfffffffc, 0x00020000);
     const uint32_t voffA = ((lane / (BN / 4)) * g.lda + (lane % (BN / 4)) * 4) * 4;
     const uint32_t voffB = ((lane / (BK / 4)) * g.ldb + (lane % (BK / 4)) * 4) * 4;
     const uint32_t rowA = g.lda * 4, rowB = g.ldb * 4;    // bytes per matrix row
@@ -189,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 #endif
         const int pc = NTW * w + ja;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(tn_smem + buf * kTileFloats + pc * 256), 16, voffA,
-                                                 (uint32_t)(((c - c_begin) * crows + pc * kRowsPerPieceA) * rowA), 0, 0);
+                                                 (uint32_t)(((c - c_begin) * kTnRows + pc * kRowsPerPieceA) * rowA), 0, 0);
     };
     auto piece_b = [&](long c, int buf, int jb) {
 #ifdef IDN_TN_TIMING_NO_PIECES
@@ -197,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 #endif
         const int pc = KTW * w + jb;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(tn_smem + buf * kTileFloats + kTnRows * BN + pc * 256), 16, voffB,
-                                                 (uint32_t)(((c - c_begin) * crows + pc * kRowsPerPieceB) * rowB), 0, 0);
+                                                 (uint32_t)(((c - c_begin) * kTnRows + pc * kRowsPerPieceB) * rowB), 0, 0);
     };
     auto piece = [&](long c, int buf, int j) {   // prologue order: A pieces, then B pieces
         if (j < NTW) piece_a(c, buf, j);
@@ -403,14 +396,11 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
         for (int b = 0; b < 4; ++b)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // this split's chunks: contiguous, or (g.interleave) every splits-th chunk starting at `split`; chunk rc sits crows rows behind rc - 1
+    const long c_begin = (long)split * g.chunks_per_split;
+    long c_end = c_begin + g.chunks_per_split;
     const long c_total = g.P / kTnRows;
-    const int n_splits = g.n_splits;
-    const long c_begin = g.interleave ? (long)split : (long)split * g.chunks_per_split;
-    const int crows = g.interleave ? n_splits * kTnRows : kTnRows;
-    long n_mine = g.interleave ? (c_total - c_begin + n_splits - 1) / n_splits : (long)g.chunks_per_split;
-    if (!g.interleave && c_begin + n_mine > c_total) n_mine = c_total - c_begin;
-    const int n_chunks = (int)n_mine;                     // >= 1 (run_tn_partials sizes the splits so)
+    if (c_end > c_total) c_end = c_total;
+    const int n_chunks = (int)(c_end - c_begin);          // >= 1 (run_tn_partials sizes the splits so)
     // Raw buffer descriptors based at this split's first row (32-bit offsets span one split).  The loads are inline asm
     // with the destination tied to the register that held the same row of the chunk before ("+v"): as a builtin the
     // reload got a fresh register and a copy at the loop end -- behind a wait for the load, a chunk early.  vmcnt is
@@ -433,7 +423,7 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
     };
     auto load_row = [&](float& dst, const tn_i32x4& rsrc, int soff) { load_row_at(dst, rsrc, soff, voff); };
     auto load_chunk = [&](int rc) {   // chunk rc of this split, clamped to its last one (re-read, never used)
-        const int base = (rc < n_chunks ? rc : n_chunks - 1) * crows;
+        const int base = (rc < n_chunks ? rc : n_chunks - 1) * kTnRows;
 #pragma unroll
         for (int p = 0; p < kTnRows; ++p) load_row(ra[p], rsrcA, (base + p) * rowA);
 #pragma unroll
@@ -515,7 +505,7 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
         // an MFMA that occupies the pipe for 32 cycles.  (Left alone, hipcc issues 40 MFMAs back to back and then 50
         // vector and memory instructions in a row, during which the matrix pipe runs dry: 57 % busy.)
         const unsigned live_mask = rc + 1 < n_chunks ? 0xffffffffu : 0u;   // the clamped re-read of the last chunk does not count
-        const int nbase = (rc + 2 < n_chunks ? rc + 2 : n_chunks - 1) * crows;   // chunk rc + 2, clamped (re-read, never used)
+        const int nbase = (rc + 2 < n_chunks ? rc + 2 : n_chunks - 1) * kTnRows;   // chunk rc + 2, clamped (re-read, never used)
         char* const dst = my_slot + (buf ^ 1) * kX6BufBytes;
         unsigned pw[2][3][8];
         float t0 = 0.f, t1 = 0.f;
@@ -645,101 +635,6 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch b) {
     red[q][o] = s;
     __syncthreads();
     if (q == 0 && live) t.out[(long)n * t.ldo + k] = (float)(((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
-}
-
-// ---------------------------------------------------------------------------
-// The two THIN weight gradients of a pass on the vector unit.  rgb_linear's is 3 x 128 (dRGB has three live columns) and the
-// direction-encoding columns of views_linears.0 are 128 x 27: as MFMA products they were a 64 x 128 and a 128 x 64 launch of
-// which 5 % / 42 % of the arithmetic was used (0.22 + 0.19 ms per step at 2-3 TB/s).  They are reductions over the points that
-// read ONE wide matrix once (v3: 512 B per point; dV0[:, :128]: 512 B) against a few values per point that every lane needs
-// (3 of dRGB; 27 of the encoding: one address per wave, served as a broadcast), so a thread owns one column of the wide matrix,
-// keeps its 3 (27) partial sums in registers and walks a block of points: HBM-shaped, 576 (640) B per point.
-// part[split][rows][cols] in the layout reduce_batch_kernel expects; fp32 partial sums over <= a few hundred points, fp64 across.
-// ---------------------------------------------------------------------------
-struct ThinArgs {
-    const float* wide; int ld_wide;     // [P, >= 128]: v3 (rgb_linear) or dV0 (direction columns)
-    const float* thin; int ld_thin;     // [P, >= 3]: dRGB, or [P, >= 27]: the direction encoding
-    float* part;                        // RGB: [splits][3][128]; DIR: [splits][128][32]
-    float* cpart;                       // RGB only: [splits][3] column sums of dRGB (rgb_linear's bias gradient); may be null
-    long P;
-    int rows_per_split;
-};
-template <bool RGB>
-__global__ __launch_bounds__(256) void thin_dw_kernel(ThinArgs g) {
-    constexpr int NT = RGB ? 3 : IDN_VIEWS_CH;        // thin values per point
-    constexpr int NQ = (NT + 3) / 4;                   // as float4 loads
-    __shared__ float red[128][NT + 1];
-    const int tid = threadIdx.x, c = tid & 127, half = tid >> 7;
-    const long r_begin = (long)blockIdx.x * g.rows_per_split;
-    long r_end = r_begin + g.rows_per_split;
-    if (r_end > g.P) r_end = g.P;
-    float acc[NT], cs[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) acc[k] = 0.f, cs[k] = 0.f;
-    // the two halves of the block take alternate rows; two rows in flight per thread
-    for (long r = r_begin + half; r < r_end; r += 4) {
-        const long r2 = r + 2;
-        const bool two = r2 < r_end;
-        const float w0 = g.wide[r * g.ld_wide + c];
-        const float w1 = two ? g.wide[r2 * g.ld_wide + c] : 0.f;
-        float t0[4 * NQ], t1[4 * NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(g.thin + r * g.ld_thin + 4 * q);
-            const f32x4 b = two ? *reinterpret_cast<const f32x4*>(g.thin + r2 * g.ld_thin + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t0[4 * q + j] = a[j], t1[4 * q + j] = b[j];
-        }
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            acc[k] = __builtin_fmaf(w0, t0[k], acc[k]);
-            acc[k] = __builtin_fmaf(w1, t1[k], acc[k]);
-            if constexpr (RGB) cs[k] += t0[k] + t1[k];
-        }
-    }
-    // the second half hands its sums to the first through LDS (fixed order: deterministic)
-    __shared__ float red_cs[NT];
-    if (half == 1) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) red[c][k] = acc[k];
-        if (RGB && c == 0) {
-#pragma unroll
-            for (int k = 0; k < NT; ++k) red_cs[k] = cs[k];
-        }
-    }
-    __syncthreads();
-    if (half == 0) {
-        if constexpr (RGB) {
-#pragma unroll
-            for (int k = 0; k < NT; ++k) g.part[((long)blockIdx.x * 3 + k) * 128 + c] = acc[k] + red[c][k];
-            if (g.cpart && c == 0) {
-#pragma unroll
-                for (int k = 0; k < NT; ++k) g.cpart[(long)blockIdx.x * 3 + k] = cs[k] + red_cs[k];
-            }
-        } else {
-            float* dst = g.part + ((long)blockIdx.x * 128 + c) * 32;
-#pragma unroll
-            for (int k = 0; k < NT; ++k) dst[k] = acc[k] + red[c][k];
-#pragma unroll
-            for (int k = NT; k < 32; ++k) dst[k] = 0.f;
-        }
-    }
-}
-constexpr int kThinSplits = 512;   // blocks of a thin product: 2 per CU, ~1150 points of the fine pass each
-template <bool RGB>
-static int launch_thin(const float* wide, int ld_wide, const float* thin, int ld_thin, int64_t P, float* part, float* cpart,
-                       int* splits_out, hipStream_t s) {
-    if ((ld_thin & 3) != 0) return fail(IDN_EINVAL, "thin_dw: row pitch %d of the narrow matrix is not a multiple of 4 floats", ld_thin);
-    int splits = kThinSplits;
-    if (splits > P) splits = (int)P;
-    const int rps = (int)((P + splits - 1) / splits);
-    splits = (int)((P + rps - 1) / rps);
-    ThinArgs g{wide, ld_wide, thin, ld_thin, part, cpart, (long)P, rps};
-    ProfScope prof(s, P, IDN_PROF_DW_GEMM);
-    hipLaunchKernelGGL(thin_dw_kernel<RGB>, dim3(splits), dim3(256), 0, s, g);
-    IDN_HIP_CHECK(hipGetLastError());
-    *splits_out = splits;
-    return IDN_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -992,26 +887,6 @@ static int env_pipe_f32() {
     return v;
 }
 static int default_gemm_pipe() { return (IDN_DW_X6 && !env_pipe_f32()) ? kPipeX6 : kPipeF32; }
-// rgb_linear's and the direction columns' weight gradients as vector-unit reductions (thin_dw_kernel) instead of MFMA products;
-// IDN_THIN_DW=mfma (read once) keeps the MFMA launches: the A/B arm
-#ifndef IDN_THIN_DW_VALU
-#define IDN_THIN_DW_VALU 1
-#endif
-// chunk assignment of the dW products: interleaved (default) or a contiguous range per split (IDN_TN_INTERLEAVE=0: the A/B arm)
-static int tn_interleave() {
-    static const int v = [] {
-        const char* e = getenv("IDN_TN_INTERLEAVE");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    return v;
-}
-static int thin_on_valu() {
-    static const int v = [] {
-        const char* e = getenv("IDN_THIN_DW");
-        return (e && e[0] == 'm') ? 0 : IDN_THIN_DW_VALU;
-    }();
-    return v;
-}
 // The 256 x 256 bf16-piece products of a pass, collected and launched as one kernel (gemm_tn_x6_kernel walks them)
 struct X6Pending {
     TNBatch b;
@@ -1093,9 +968,7 @@ static int run_tn_partials(X6Pending& x6, const float* A, int lda, int N, const 
     if (splits < 1) splits = 1;
     const int cps = (int)((chunks + splits - 1) / splits);
     splits = (int)((chunks + cps - 1) / cps);
-    // interleaved chunk assignment needs every row offset of the matrices in 31 bits (the kernels address a split from its first chunk)
-    const int interleave = tn_interleave() && (int64_t)P * (lda > ldb ? lda : ldb) * 4 < ((int64_t)1 << 31) ? 1 : 0;
-    TNArgs g{A, lda, B, ldb, part, N, K, (long)P, cps, cpart, 0, 0, 0, interleave, splits};
+    TNArgs g{A, lda, B, ldb, part, N, K, (long)P, cps, cpart, 0, 0, 0};
     if (B2) {   // byte offsets from the lower of the two addresses (buffer offsets are unsigned)
         const float* base = B < B2 ? B : B2;
         const int64_t o0 = (int64_t)(B - base) * 4, o1 = (int64_t)(B2 - base) * 4;
@@ -1240,18 +1113,7 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
     }
     // weight and bias gradients: dW_l = delta_l^T a_{l-1} (contraction over the points), db_l = column sums
     ReduceQueue q(w.part, w.cpart, kX6ItemsPerPass);
-    if (thin_on_valu()) {   // rgb_linear: 3 x 128, a reduction over the points on the vector unit (thin_dw_kernel)
-        int splits = 0;
-        float* part = q.part_next;
-        float* cpart = q.cpart_next;
-        TRY(launch_thin<true>(v_l(3), 128, w.dRGB, 64, Pp, part, cpart, &splits, s));
-        q.part_next += (size_t)splits * 3 * 128;
-        q.cpart_next += (size_t)splits * 3;
-        TRY(q.add(cpart, splits, 1, 3, 0, 0, gr.rgb_b, 3, 1, 3));
-        TRY(q.add(part, splits, 3, 128, 0, 0, gr.rgb_w, 128, 3, 128));
-    } else {
-        TRY(run_tn(q, w.dRGB, 64, 64, v_l(3), 128, 128, Pp, gr.rgb_w, 128, 3, 128, s, gr.rgb_b, 3));
-    }
+    TRY(run_tn(q, w.dRGB, 64, 64, v_l(3), 128, 128, Pp, gr.rgb_w, 128, 3, 128, s, gr.rgb_b, 3));
     // views_linears.2 and .1 (128 x 128 each): on the bf16 pipe ONE 256 x 256 launch whose A is the side-by-side delta matrix and
     // whose B columns come from the two activation matrices (v2 | v1) -- the weight gradients are its diagonal blocks, and 1 KB per
     // point and layer is read once by a kernel that runs at the HBM rate (two fp32-MFMA launches took 1.7x as long).  The
@@ -1282,15 +1144,7 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
         TRY(q.add(part, splits, 256, 256, 0, 0, gr.views_w[0], ldv, 128, 256));
         TRY(q.add(part, splits, 256, 256, kSigmaChannel, 0, gr.alpha_w, 256, 1, 256));
     }
-    if (thin_on_valu()) {   // the direction-encoding columns of views_linears.0: 128 x 27, the same way
-        int splits = 0;
-        float* part = q.part_next;
-        TRY(launch_thin<false>(w.dV0, 256, act(kActDir), 64, Pp, part, nullptr, &splits, s));
-        q.part_next += (size_t)splits * 128 * 32;
-        TRY(q.add(part, splits, 128, 32, 0, 0, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH));
-    } else {
-        TRY(run_tn(q, w.dV0, 256, 128, act(kActDir), 64, 64, Pp, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH, s));
-    }
+    TRY(run_tn(q, w.dV0, 256, 128, act(kActDir), 64, 64, Pp, gr.views_w[0] + IDN_W, ldv, 128, IDN_VIEWS_CH, s));
     for (int l = 7; l >= 1; --l) {
         const float* cur = w.dA[l];
         if (l == 5) {
