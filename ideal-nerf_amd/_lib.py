@@ -46,6 +46,14 @@ class RenderArgs(C.Structure):
                 ("lindisp", C.c_int), ("white_bkgd", C.c_int), ("noise_coarse", fp), ("noise_fine", fp), ("fused_march", C.c_int)]
 
 
+class AudioNetParams(C.Structure):
+    _fields_ = [("conv_w", fp * 4), ("conv_b", fp * 4), ("fc_w", fp * 2), ("fc_b", fp * 2), ("dim_aud", C.c_int)]
+
+
+class AudioNetGrads(C.Structure):
+    _fields_ = [("conv_w", fp * 4), ("conv_b", fp * 4), ("fc_w", fp * 2), ("fc_b", fp * 2)]
+
+
 class Frame(C.Structure):
     _fields_ = [("c2w", C.c_float * 12), ("H", C.c_int), ("W", C.c_int), ("focal", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("near_", C.c_float), ("far_", C.c_float), ("row0", C.c_int), ("nrows", C.c_int), ("rays_out", fp)]
@@ -78,6 +86,9 @@ PROTOTYPES = {
     "idealnerf_render_rays_fwd": (C.c_int, [C.POINTER(RenderArgs), fp]),
     "idealnerf_render_frame_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "idealnerf_render_frame_fwd": (C.c_int, [C.POINTER(RenderArgs), C.POINTER(Frame), fp]),
+    "idealnerf_audio_net_saved_floats": (C.c_size_t, [C.c_int]),
+    "idealnerf_audio_net_fwd": (C.c_int, [C.POINTER(AudioNetParams), fp, C.c_int, fp, fp, fp]),
+    "idealnerf_audio_net_bwd": (C.c_int, [C.POINTER(AudioNetParams), C.POINTER(AudioNetGrads), fp, fp, fp, C.c_int, fp]),
     "idealnerf_train_acts_floats": (C.c_size_t, [C.c_int64]),
     "idealnerf_query_rays_train_fwd": (C.c_int, [fp, fp, C.c_int, fp, fp, C.c_int64, C.c_int, fp, fp, fp]),
     "idealnerf_pass_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libidealnerf.so")
-SOURCES = ["mlp_f32.hip", "mlp_bf16x3.hip", "mlp_fp16x3.hip", "mlp_bf16x6.hip", "render_fused.hip", "mlp_f32_bwd.hip", "prep.hip", "composite.hip", "train.hip", "capi.hip"]
+SOURCES = ["mlp_f32.hip", "mlp_bf16x3.hip", "mlp_fp16x3.hip", "mlp_bf16x6.hip", "render_fused.hip", "mlp_f32_bwd.hip", "prep.hip", "composite.hip", "audio.hip", "train.hip", "capi.hip"]
 # -ffp-contract=off: sample positions feed index decisions and must round like the
 # reference's chain of eager ops (DESIGN.md "numerics"); MFMA is unaffected.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -165,6 +165,16 @@ int idealnerf_coarse_depths(const float* rays, const float* t_vals, const float*
     return launch_coarse_depths(rays, t_vals, t_rand, n_rays, n_samples, lindisp, z, (hipStream_t)stream);
 }
 
+size_t idealnerf_audio_net_saved_floats(int n_windows) { return audio_net_saved_floats(n_windows); }
+int idealnerf_audio_net_fwd(const idn_audio_net_params* p, const float* windows, int n_windows, float* out, float* saved,
+                            void* stream) {
+    return launch_audio_net_fwd(p, windows, n_windows, out, saved, (hipStream_t)stream);
+}
+int idealnerf_audio_net_bwd(const idn_audio_net_params* p, const idn_audio_net_grads* grads, const float* windows,
+                            const float* saved, const float* d_out, int n_windows, void* stream) {
+    return launch_audio_net_bwd(p, grads, windows, saved, d_out, n_windows, (hipStream_t)stream);
+}
+
 int idealnerf_to8b(const float* rgb, int64_t n_pixels, int swap_rb, uint8_t* out, int* nonfinite_flag, void* stream) {
     if (n_pixels < 0) return fail(IDN_EINVAL, "n_pixels < 0");
     if (n_pixels == 0) return IDN_OK;

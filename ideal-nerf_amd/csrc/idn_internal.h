@@ -213,6 +213,10 @@ int launch_frame_rays(const float* c2w, int H, int W, float focal, float cx, flo
                       int row0, int nrows, float* rays_out, hipStream_t s);
 int launch_frame_rays_pixels(const float* c2w_host, int H, int W, float focal, float cx, float cy, float near_, float far_,
                              int64_t pix0, int npix, float* rays_out, hipStream_t s);
+size_t audio_net_saved_floats(int n);
+int launch_audio_net_fwd(const idn_audio_net_params* p, const float* windows, int n, float* out, float* saved, hipStream_t s);
+int launch_audio_net_bwd(const idn_audio_net_params* p, const idn_audio_net_grads* g, const float* windows, const float* saved,
+                         const float* d_out, int n, hipStream_t s);
 int launch_to8b(const float* rgb, int64_t n_pixels, int swap_rb, unsigned char* out, int* flag, hipStream_t s);
 int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays, int S,
                          int lindisp, float* z, hipStream_t s);

@@ -316,7 +316,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 #ifdef IDN_DIAG
     __builtin_amdgcn_s_waitcnt(0);
     TN_STAMP(dg_t2);
-    if (NTW == 4 && KTW == 4 && tid == 0) {
+#ifndef IDN_DIAG_KTW
+#define IDN_DIAG_KTW 4      // which 4-row-tile shape the stamps are collected for: <4,4> (default) or <4,1> (-DIDN_DIAG_KTW=1)
+#endif
+    if (NTW == 4 && KTW == IDN_DIAG_KTW && tid == 0) {
         atomicAdd(&g_tn_diag[0], dg_t2 - dg_t0);
         atomicAdd(&g_tn_diag[1], dg_wait);
         atomicAdd(&g_tn_diag[2], dg_loop);

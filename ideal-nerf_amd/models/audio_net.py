@@ -1,13 +1,42 @@
 """Per-frame audio latent producers, state_dict compatible with the reference's
 ``models/audio_net.py`` (AudioNet :43-69, AudioAttNet :8-36, DeepSpeechAudNet :72-87).
 
-They run once per frame on a [<=8, 16, 29] window and cost nothing next to the per-ray
-path, so they stay plain PyTorch-ROCm modules: device plumbing around
-the HIP kernels, not part of the measured hot loop.
+They run once per frame on a [<=8, 16, 29] window and cost nothing next to the per-ray path of a FRAME (SURVEY
+section 2).  In a TRAINING STEP, though, AudioNet's ~50 eager launches (forward + backward) were a third of the step's
+small launches, each a few microseconds behind a dispatch gap: on the GPU `AudioNet.forward` therefore runs as one HIP
+kernel and its backward as one (csrc/audio.hip, `idealnerf_audio_net_fwd / _bwd`); on the CPU, for other window sizes and
+for more than eight windows with gradients it is the plain PyTorch module below.  The attention smoother and the
+DeepSpeech squeeze stay PyTorch-ROCm.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+FUSED_AUDIO_NET = os.environ.get("IDN_FUSED_AUDIO_NET", "1") != "0"   # read once: 0 keeps the eager module (the A/B arm)
+
+
+class _AudioNetFn(torch.autograd.Function):
+    """AudioNet on [n, 16, 29] windows: one kernel forward, one backward (parameter gradients; the windows are data)."""
+
+    @staticmethod
+    def forward(ctx, windows, dim_aud, *params):
+        from .. import ops
+        save = any(ctx.needs_input_grad[2:])     # (grad mode is off inside forward: ask autograd what it will want back)
+        with torch.no_grad():
+            out, saved = ops.audio_net_fwd([p.detach() for p in params], windows, dim_aud, save=save)
+        ctx.dim_aud = dim_aud
+        if save:
+            ctx.save_for_backward(windows, saved, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        windows, saved, *params = ctx.saved_tensors
+        grads = ops.audio_net_bwd([p.detach() for p in params], windows, saved, g.contiguous().to(torch.float32), ctx.dim_aud)
+        return (None, None, *grads)
 
 
 def _conv1d_k3(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
@@ -63,7 +92,18 @@ class AudioNet(nn.Module):
         self.encoder_conv = nn.Sequential(*layers)
         self.encoder_fc1 = nn.Sequential(nn.Linear(64, 64), nn.LeakyReLU(0.02, True), nn.Linear(64, dim_aud))
 
+    def _fused_params(self):
+        return [t for i in (0, 2, 4, 6) for t in (self.encoder_conv[i].weight, self.encoder_conv[i].bias)] + \
+               [t for i in (0, 2) for t in (self.encoder_fc1[i].weight, self.encoder_fc1[i].bias)]
+
     def forward(self, x):  # x: [n, 16, 29]
+        if (FUSED_AUDIO_NET and x.is_cuda and self.win_size == 16 and x.dim() == 3 and tuple(x.shape[1:]) == (16, 29)
+                and x.dtype == torch.float32 and self.dim_aud <= 128 and not x.requires_grad):
+            params = self._fused_params()
+            needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            from ..ops import AUDIO_NET_MAX_BWD_WINDOWS
+            if not needs_grad or x.shape[0] <= AUDIO_NET_MAX_BWD_WINDOWS:
+                return _AudioNetFn.apply(x.contiguous(), self.dim_aud, *params).squeeze()
         half_w = int(self.win_size / 2)
         x = x[:, 8 - half_w:8 + half_w, :].permute(0, 2, 1)
         x = _run_convnet(self.encoder_conv, x).squeeze(-1)

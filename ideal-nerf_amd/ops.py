@@ -354,6 +354,59 @@ def dw_gemm(delta, acts, pipe=0, with_bias=True):
     return dW, db
 
 
+AUDIO_NET_MAX_BWD_WINDOWS = 8
+
+
+def _audio_params_struct(params, dim_aud):
+    """params: encoder_conv.{0,2,4,6}.{weight,bias} then encoder_fc1.{0,2}.{weight,bias} (12 tensors, nn layout)."""
+    shapes = [(32, 29, 3), (32,), (32, 32, 3), (32,), (64, 32, 3), (64,), (64, 64, 3), (64,), (64, 64), (64,), (dim_aud, 64), (dim_aud,)]
+    if len(params) != 12:
+        raise IdealNerfError(f"AudioNet has 12 parameter tensors, got {len(params)}")
+    for i, (t, shp) in enumerate(zip(params, shapes)):
+        _shape(t, f"AudioNet parameter {i}", *shp)
+    p = _lib.AudioNetParams()
+    for i in range(4):
+        p.conv_w[i], p.conv_b[i] = _ptr(params[2 * i], "conv weight"), _ptr(params[2 * i + 1], "conv bias")
+    for i in range(2):
+        p.fc_w[i], p.fc_b[i] = _ptr(params[8 + 2 * i], "fc weight"), _ptr(params[9 + 2 * i], "fc bias")
+    p.dim_aud = int(dim_aud)
+    return p
+
+
+def audio_net_fwd(params, windows, dim_aud, save=False):
+    """AudioNet.forward (models/audio_net.py:43-69) on [n, 16, 29] windows as one kernel -> ([n, dim_aud], saved or None)."""
+    lib = _lib.load()
+    _shape(windows, "windows", None, 16, 29)
+    n = windows.shape[0]
+    with _Launch(windows, *params) as L:
+        p = _audio_params_struct(params, dim_aud)
+        out = torch.empty((n, dim_aud), dtype=torch.float32, device=windows.device)
+        saved = torch.empty(lib.idealnerf_audio_net_saved_floats(n), dtype=torch.float32, device=windows.device) if save else None
+        check(lib.idealnerf_audio_net_fwd(C.byref(p), _ptr(windows, "windows"), n, out.data_ptr(),
+                                          None if saved is None else saved.data_ptr(), L.stream))
+    return out, saved
+
+
+def audio_net_bwd(params, windows, saved, d_out, dim_aud):
+    """-> the 12 parameter gradients (summed over the n <= 8 windows), in the order of `params`."""
+    lib = _lib.load()
+    n = windows.shape[0]
+    _shape(windows, "windows", None, 16, 29)
+    _shape(d_out, "d_out", n, dim_aud)
+    _shape(saved, "saved", lib.idealnerf_audio_net_saved_floats(n))
+    with _Launch(windows, saved, d_out, *params) as L:
+        p = _audio_params_struct(params, dim_aud)
+        grads = [torch.empty_like(t) for t in params]
+        g = _lib.AudioNetGrads()
+        for i in range(4):
+            g.conv_w[i], g.conv_b[i] = grads[2 * i].data_ptr(), grads[2 * i + 1].data_ptr()
+        for i in range(2):
+            g.fc_w[i], g.fc_b[i] = grads[8 + 2 * i].data_ptr(), grads[9 + 2 * i].data_ptr()
+        check(lib.idealnerf_audio_net_bwd(C.byref(p), C.byref(g), _ptr(windows, "windows"), _ptr(saved, "saved"), _ptr(d_out, "d_out"),
+                                          n, L.stream))
+    return grads
+
+
 _workspaces: Dict[tuple, torch.Tensor] = {}
 
 

@@ -346,6 +346,33 @@ int idealnerf_dw_gemm(const float* delta, int ld_delta, const float* acts, int l
                       int pipe, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * AudioNet.forward (models/audio_net.py:43-69: the per-frame audio latent of audio_exp_nerf.py:258-259, or of the eight windows
+ * under the attention smoother, :235-257) as ONE kernel, and its backward as one: windows [n, 16, 29] (win_size 16) ->
+ * out [n, dim_aud].  Parameters in nn.Conv1d / nn.Linear layout ([C_out, C_in, 3] / [out, in], fp32, contiguous):
+ * encoder_conv.{0,2,4,6} and encoder_fc1.{0,2}.  `saved` (NULL for inference) receives the 640 post-activations per window the
+ * backward needs (idealnerf_audio_net_saved_floats).  The backward (n <= 8 windows) OVERWRITES every gradient buffer with the
+ * sum over the windows; the windows themselves are data (no gradient).
+ */
+typedef struct idn_audio_net_params {
+    const float* conv_w[4];
+    const float* conv_b[4];
+    const float* fc_w[2];
+    const float* fc_b[2];
+    int dim_aud;
+} idn_audio_net_params;
+typedef struct idn_audio_net_grads {
+    float* conv_w[4];
+    float* conv_b[4];
+    float* fc_w[2];
+    float* fc_b[2];
+} idn_audio_net_grads;
+size_t idealnerf_audio_net_saved_floats(int n_windows);
+int idealnerf_audio_net_fwd(const idn_audio_net_params* p, const float* windows, int n_windows, float* out, float* saved,
+                            void* stream);
+int idealnerf_audio_net_bwd(const idn_audio_net_params* p, const idn_audio_net_grads* grads, const float* windows,
+                            const float* saved, const float* d_out, int n_windows, void* stream);
+
+/*
  * Frame tail.  to8b = `(255 * np.clip(x, 0, 1)).astype(np.uint8)` (NeRFs/HeadNeRF/helper.py:154) on
  * the device: rgb [n_pixels,3] fp32 -> out [n_pixels,3] u8, bit-identical to numpy for finite input;
  * swap_rb != 0 writes the channels in reverse order (the cv2.cvtColor the reference leaves

@@ -365,6 +365,45 @@ def test_audio_nets_on_gpu_match_reference_and_conv_autograd(idn, dev, golden):
     np.testing.assert_allclose(feats.cpu().numpy(), c["out"], rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("n,dim_aud", [(1, 64), (8, 64), (3, 76), (40, 64)])
+def test_fused_audio_net_matches_the_eager_module(idn, dev, n, dim_aud):
+    """AudioNet (models/audio_net.py:43-69) on the GPU is one HIP kernel forward and one backward (csrc/audio.hip); the eager
+    PyTorch module with the same parameters is the yardstick: outputs to 2e-6, every parameter gradient to 1e-5 of its largest
+    entry, for one window (a frame / a training step), the smoother's eight, and -- forward only -- a whole clip."""
+    from idealnerf_amd.models import audio_net as AN
+    torch.manual_seed(n)
+    net = AN.AudioNet(dim_aud, 16).to(dev)
+    x = torch.randn(n, 16, 29, device=dev)
+    w = torch.randn(n, dim_aud, device=dev).squeeze()
+
+    def run(fused):
+        old, AN.FUSED_AUDIO_NET = AN.FUSED_AUDIO_NET, fused
+        try:
+            for p_ in net.parameters():
+                p_.grad = None
+            if n > 8:
+                with torch.no_grad():
+                    return net(x), None
+            out = net(x)
+            (out * w).sum().backward()
+            return out.detach(), [p_.grad.clone() for p_ in net.parameters()]
+        finally:
+            AN.FUSED_AUDIO_NET = old
+
+    out_f, g_f = run(True)
+    out_e, g_e = run(False)
+    assert out_f.shape == out_e.shape == ((dim_aud,) if n == 1 else (n, dim_aud))
+    assert rel_err(out_f, out_e) < 2e-6
+    if g_f is not None:
+        for (name, _), a, b in zip(net.named_parameters(), g_f, g_e):
+            assert rel_err(a, b) < 1e-5, name
+        out2, g2 = run(True)     # deterministic: no atomics
+        assert torch.equal(out2, out_f) and all(torch.equal(a, b) for a, b in zip(g2, g_f))
+    else:   # more than eight windows with gradients fall back to the eager module (the backward kernel holds eight windows in LDS)
+        net(x).sum().backward()
+        assert all(p_.grad is not None for p_ in net.parameters())
+
+
 # --------------------------------------------------------------------------- BASELINE configs[3]: Obama, by name
 @pytest.mark.parametrize("cfg_name", ["NeRFs/HeadNeRF/configs/audio_expr_nerf/obama/paper_model.txt",
                                       "NeRFs/HeadNeRF/configs/audio_expr_nerf/obama3/paper_model/torso_bg.txt",

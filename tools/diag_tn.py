@@ -31,4 +31,4 @@ print(json.dumps({"blocks": blocks, "chunks": chunks, "cycles_per_block": tot / 
                   "cycles_per_chunk_in_loop": loop / max(chunks, 1), "cycles_per_chunk_waiting": wait / max(chunks, 1),
                   "share_wait": wait / tot, "share_loop": loop / tot, "share_epilogue": epi / tot,
                   "share_prologue": (tot - wait - loop - epi) / tot,
-                  "ideal_cycles_per_chunk": 8 * 16 * 64}))
+                  "ideal_cycles_per_chunk_4x4": 8 * 16 * 64, "ideal_cycles_per_chunk_4x1": 8 * 4 * 64}))
