@@ -129,13 +129,19 @@ __device__ unsigned long long g_tn_diag[8];   // total, wait (vmcnt + barrier), 
 // shape (32 KiB per chunk, 16 MFMAs per point pair and wave) runs NB = 3; the narrow shapes do a quarter of the arithmetic per
 // byte (a 256 x 64 chunk is 20 KiB for 4 MFMAs per point pair: 1 us of matrix time, less than a loaded HBM round trip) and
 // run a deeper ring, so that several chunks per workgroup are in flight.
-template <int NTW, int KTW, int NB = kTnBufs>
+// R = points per chunk (a multiple of 16).  A chunk costs ~1 000 cycles besides its MFMAs (the barrier and its skew, the first LDS
+// reads behind it with nothing to overlap, the drain of the prefetched reads at its end: in-kernel stamps, tools/diag_tn.py:
+// 3 007 cycles per 16-point chunk of the 256 x 64 shape against 2 048 of MFMAs), so the shapes with few MFMAs per point take
+// larger chunks.
+template <int NTW, int KTW, int NB = kTnBufs, int R = kTnRows>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
-    static_assert(NB >= 3 && (NB - 2) * (NTW + KTW) <= 63, "vmcnt is a 6-bit field");
+    static_assert(R % 16 == 0, "chunks are multiples of 16 points");
+    constexpr int NPA = NTW * R / 16, NPB = KTW * R / 16;   // 1-KiB pieces of the A / B tile per wave and chunk
+    static_assert(NB >= 3 && (NB - 2) * (NPA + NPB) <= 63, "vmcnt is a 6-bit field");
     constexpr int BN = 64 * NTW, BK = 64 * KTW;
-    constexpr int kTileFloats = kTnRows * (BN + BK);       // one chunk: A tile then B tile
-    constexpr int kSteps = kTnRows / 2;                    // point-pairs per chunk
-    constexpr int NP = NTW + KTW;                          // 1-KiB pieces per wave and chunk (<= kSteps)
+    constexpr int kTileFloats = R * (BN + BK);       // one chunk: A tile then B tile
+    constexpr int kSteps = R / 2;                    // point-pairs per chunk
+    constexpr int NP = NPA + NPB;                          // 1-KiB pieces per wave and chunk (<= kSteps)
     static_assert(NP <= kSteps, "at most one piece per step");
     extern __shared__ __attribute__((aligned(16))) float tn_smem[];  // NB * kTileFloats
     const int tid = threadIdx.x, lane = tid & 63;
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     TN_STAMP(dg_t0);
     const long c_begin = (long)split * g.chunks_per_split;
     long c_end = c_begin + g.chunks_per_split;
-    const long c_total = g.P / kTnRows;
+    const long c_total = g.P / R;
     if (c_end > c_total) c_end = c_total;
     const bool colsum_block = g.cpart != nullptr && blockIdx.y == 0;   // block-uniform
     const bool do_colsum = colsum_block && tid < BN;
@@ -168,8 +174,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
     constexpr int kRowsPerPieceA = 256 / BN > 0 ? 256 / BN : 1, kRowsPerPieceB = 256 / BK > 0 ? 256 / BK : 1;
     // descriptors based at this block's first row: the 32-bit piece offsets then span one split (tens of MB), not the
     // whole matrix (which passes 4 GB from 4 M points on)
-    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + n0 + c_begin * kTnRows * (long)g.lda), 0, 0xfffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + k0 + c_begin * kTnRows * (long)g.ldb), 0, 0xfffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + n0 + c_begin * R * (long)g.lda), 0, 0xfffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + k0 + c_begin * R * (long)g.ldb), 0, 0xfffffffc, 0x00020000);
     const uint32_t voffA = ((lane / (BN / 4)) * g.lda + (lane % (BN / 4)) * 4) * 4;
     const uint32_t voffB = ((lane / (BK / 4)) * g.ldb + (lane % (BK / 4)) * 4) * 4;
     const uint32_t rowA = g.lda * 4, rowB = g.ldb * 4;    // bytes per matrix row
@@ -180,26 +186,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
 #ifdef IDN_TN_TIMING_NO_PIECES   // timing-only experiment (wrong results): the GEMM without its HBM traffic
         if (c > c_begin + 1) return;
 #endif
-        const int pc = NTW * w + ja;
+        const int pc = NPA * w + ja;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(tn_smem + buf * kTileFloats + pc * 256), 16, voffA,
-                                                 (uint32_t)(((c - c_begin) * kTnRows + pc * kRowsPerPieceA) * rowA), 0, 0);
+                                                 (uint32_t)(((c - c_begin) * R + pc * kRowsPerPieceA) * rowA), 0, 0);
     };
     auto piece_b = [&](long c, int buf, int jb) {
 #ifdef IDN_TN_TIMING_NO_PIECES
         if (c > c_begin + 1) return;
 #endif
-        const int pc = KTW * w + jb;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(tn_smem + buf * kTileFloats + kTnRows * BN + pc * 256), 16, voffB,
-                                                 (uint32_t)(((c - c_begin) * kTnRows + pc * kRowsPerPieceB) * rowB), 0, 0);
+        const int pc = NPB * w + jb;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(tn_smem + buf * kTileFloats + R * BN + pc * 256), 16, voffB,
+                                                 (uint32_t)(((c - c_begin) * R + pc * kRowsPerPieceB) * rowB), 0, 0);
     };
     auto piece = [&](long c, int buf, int j) {   // prologue order: A pieces, then B pieces
-        if (j < NTW) piece_a(c, buf, j);
-        else if (j < NP) piece_b(c, buf, j - NTW);
+        if (j < NPA) piece_a(c, buf, j);
+        else if (j < NP) piece_b(c, buf, j - NPA);
     };
     // LDS byte addresses of this lane's operands of point-pair 0 in buffer 0: row hh, columns NTW * (32 wr + i) ..
     const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)tn_smem;
     const uint32_t a_addr0 = smem0 + (hh * BN + NTW * (32 * wr + i)) * 4;
-    const uint32_t b_addr0 = smem0 + (kTnRows * BN + hh * BK + KTW * (32 * wc + i)) * 4;
+    const uint32_t b_addr0 = smem0 + (R * BN + hh * BK + KTW * (32 * wc + i)) * 4;
     // every chunk's NP pieces are issued even past the end of the split (clamped to its last chunk: re-read, never used), so
     // that exactly (NB - 2) * NP younger vector-memory operations are in flight at every chunk's wait
     for (int ahead = 0; ahead < NB - 1; ++ahead)
@@ -220,17 +226,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
         const int buf2 = buf >= 1 ? buf - 1 : NB - 1;   // (buf + NB - 1) % NB: the buffer chunk c - 1 has just left
         const long cnext = c + NB - 1 < c_end ? c + NB - 1 : c_end - 1;   // clamped: the re-read of the last chunk is never used
         constexpr bool more = true;
-        // The delta tile is in LDS anyway: its column sums are the bias gradient.  The kTnRows reads of column
+        // The delta tile is in LDS anyway: its column sums are the bias gradient.  The R reads of column
         // `tid` go out first (inline asm, like the operand reads) and are added after the first counted wait of
         // the loop below, which covers them (LDS returns in order): read by plain loads they parked every wave
         // for two LDS round trips per chunk, 5 % of it.
-        float cs[kTnRows];
-        if (colsum_block) {
-            const uint32_t caddr = smem0 + buf * (kTileFloats * 4) + ccol * 4;
-            tn_static_for<kTnRows>([&](auto R) {
-                lds_read_f32<decltype(R)::value * BN * 4>(cs[decltype(R)::value], caddr);
+        // (In batches of 16 rows: batch k + 1 is issued at the end of loop iteration k -- in front of that iteration's operand
+        // reads, whose counted wait in iteration k + 1 then covers it -- into the registers batch k has just been added from.)
+        float cs[16];
+        auto cs_issue = [&](int batch) {
+            const uint32_t caddr = smem0 + buf * (kTileFloats * 4) + ccol * 4 + batch * (16 * BN * 4);
+            tn_static_for<16>([&](auto Row) {
+                lds_read_f32<decltype(Row)::value * BN * 4>(cs[decltype(Row)::value], caddr);
             });
-        }
+        };
+        static_assert(R / 16 <= kSteps / 4, "one batch of column reads per iteration of the first half loop");
+        if (colsum_block) cs_issue(0);
         // kSteps point-pairs, two per loop iteration (one per register buffer); the loop is kept rolled: fully
         // unrolled, hipcc shuffles the 256 accumulator registers between steps (~500 v_accvgpr_mov per chunk)
         LdsVec<NTW> a0v, a1v;
@@ -250,22 +260,81 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
         a0v.template issue<0>(pa);
         b0v.template issue<0>(pb);
         // first half of the chunk: the A pieces of chunk c + 2 (one per point pair), second half: its B pieces
-        static_assert(NTW <= kSteps / 2 && KTW <= kSteps / 2, "pieces of one matrix fit one half of a chunk");
+        static_assert(NPA <= kSteps / 2 && NPB <= kSteps / 2, "pieces of one matrix fit one half of a chunk");
+        constexpr int M = NTW * KTW;        // MFMAs per point pair
+        if constexpr (M >= 4) {
+            // The fp32 MFMA issues every 64 cycles and everything else issues IN ORDER between two of them: left to hipcc, a
+            // pair's MFMAs go out back to back and its ~20 other instructions (operand reads, the LDS-DMA piece with its scalar
+            // address arithmetic, pointer updates, the loop branch) follow in one run -- longer than the 60 cycles the last MFMA
+            // leaves free, so the matrix pipe idled ~120 cycles per point pair (in-kernel stamps: 376 cycles per pair of the
+            // 256 x 64 shape against 256; the same ~120 on the 1 024 of the 256 x 256 shape).  The other work is therefore cut into
+            // three slots placed behind the first three MFMAs of a pair, with scheduling fences; the pair's operands are read in
+            // the shadow of the pair before (three MFMAs = 190 cycles ahead of their first use).
+            auto step = [&](LdsVec<NTW>& ca, LdsVec<KTW>& cb, auto&& side0, auto&& side1, auto&& side2) {
+                lds_retire<0>(ca, cb);
+                tn_static_for<M>([&](auto M_) {
+                    constexpr int m = decltype(M_)::value, x = m / KTW, y = m % KTW;
+                    acc[x][y] = mfma32(ca.get(x), cb.get(y), acc[x][y]);
+                    if constexpr (m < 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (m == 0) side0();
+                        if constexpr (m == 1) side1();
+                        if constexpr (m == 2) side2();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            };
+#pragma unroll 1
+            for (int it = 0; it < kSteps / 4; ++it) {
+                step(a0v, b0v,
+                     [&]() { a1v.template issue<kStepA>(pa); b1v.template issue<kStepB>(pb); },
+                     [&]() { if (more && 2 * it < NPA) piece_a(cnext, buf2, 2 * it); },
+                     [&]() {
+                         if (colsum_block && it < R / 16) {   // batch `it` of the column reads is older than a0v / b0v: retired with them
+                             tn_static_for<16>([&](auto Row) { csum += landed(cs[decltype(Row)::value]); });
+                         }
+                         pa += 2 * kStepA;
+                         pb += 2 * kStepB;
+                     });
+                step(a1v, b1v,
+                     [&]() { a0v.template issue<0>(pa); b0v.template issue<0>(pb); },
+                     [&]() { if (more && 2 * it + 1 < NPA) piece_a(cnext, buf2, 2 * it + 1); },
+                     [&]() { if (colsum_block && it + 1 < R / 16) cs_issue(it + 1); });
+            }
+#pragma unroll 1
+            for (int it = 0; it < kSteps / 4; ++it) {
+                const bool last = it == kSteps / 4 - 1;
+                step(a0v, b0v,
+                     [&]() { a1v.template issue<kStepA>(pa); b1v.template issue<kStepB>(pb); },
+                     [&]() { if (more && 2 * it < NPB) piece_b(cnext, buf2, 2 * it); },
+                     [&]() {
+                         // the pair after next; past the last pair the read is repeated on the current rows (never used):
+                         // one loop shape for all iterations keeps the accumulators where they are
+                         pa = last ? pa : pa + 2 * kStepA;
+                         pb = last ? pb : pb + 2 * kStepB;
+                     });
+                step(a1v, b1v,
+                     [&]() { a0v.template issue<0>(pa); b0v.template issue<0>(pb); },
+                     [&]() { if (more && 2 * it + 1 < NPB) piece_b(cnext, buf2, 2 * it + 1); },
+                     [&]() {});
+            }
+        } else {
 #pragma unroll 1
         for (int it = 0; it < kSteps / 4; ++it) {
             a1v.template issue<kStepA>(pa);
             b1v.template issue<kStepB>(pb);
-            if (more && 2 * it < NTW) piece_a(cnext, buf2, 2 * it);
+            if (more && 2 * it < NPA) piece_a(cnext, buf2, 2 * it);
             lds_retire<2>(a0v, b0v);
-            if (colsum_block && it == 0) {   // the column reads were issued before a0v / b0v: they have landed too
-                tn_static_for<kTnRows>([&](auto R) { csum += landed(cs[decltype(R)::value]); });
+            if (colsum_block && it < R / 16) {   // batch `it` of the column reads was issued before a0v / b0v: it has landed too
+                tn_static_for<16>([&](auto Row) { csum += landed(cs[decltype(Row)::value]); });
             }
             mm(a0v, b0v);
             pa += 2 * kStepA;
             pb += 2 * kStepB;
+            if (colsum_block && it + 1 < R / 16) cs_issue(it + 1);
             a0v.template issue<0>(pa);
             b0v.template issue<0>(pb);
-            if (more && 2 * it + 1 < NTW) piece_a(cnext, buf2, 2 * it + 1);
+            if (more && 2 * it + 1 < NPA) piece_a(cnext, buf2, 2 * it + 1);
             lds_retire<2>(a1v, b1v);
             mm(a1v, b1v);
         }
@@ -273,7 +342,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
         for (int it = 0; it < kSteps / 4; ++it) {
             a1v.template issue<kStepA>(pa);
             b1v.template issue<kStepB>(pb);
-            if (more && 2 * it < KTW) piece_b(cnext, buf2, 2 * it);
+            if (more && 2 * it < NPB) piece_b(cnext, buf2, 2 * it);
             lds_retire<2>(a0v, b0v);
             mm(a0v, b0v);
             // the pair after next; past the last pair the read is repeated on the current rows (never used):
@@ -283,9 +352,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
             pb = last ? pb : pb + 2 * kStepB;
             a0v.template issue<0>(pa);
             b0v.template issue<0>(pb);
-            if (more && 2 * it + 1 < KTW) piece_b(cnext, buf2, 2 * it + 1);
+            if (more && 2 * it + 1 < NPB) piece_b(cnext, buf2, 2 * it + 1);
             lds_retire<2>(a1v, b1v);
             mm(a1v, b1v);
+        }
         }
         lds_retire<0>(a0v, b0v);   // drain the repeated read before these registers are reused
         buf = buf + 1 == NB ? 0 : buf + 1;
@@ -840,7 +910,14 @@ constexpr size_t kPartFloatsPerSplit = 9 * 65536 + 6 * 16384 + 4 * 8192;   // (t
 // The narrow shapes (256 x 64, 128 x 64, 64 x 128 outputs: pts_linears.0, the encoding columns of pts_linears.5, the direction
 // columns of views_linears.0, rgb_linear) are HBM-shaped: ring depth and workgroups per CU decide how many bytes they keep in flight
 #ifndef IDN_TN_NARROW_BUFS
-#define IDN_TN_NARROW_BUFS 6
+#define IDN_TN_NARROW_BUFS 3
+#endif
+// points per chunk of the narrow shapes: 256 x 64 (40 KiB per 32-point chunk) and 128 x 64 / 64 x 128 (48 KiB per 64-point chunk)
+#ifndef IDN_TN_ROWS_4x1
+#define IDN_TN_ROWS_4x1 32
+#endif
+#ifndef IDN_TN_ROWS_THIN
+#define IDN_TN_ROWS_THIN 64
 #endif
 #ifndef IDN_TN_NARROW_SPLITS
 #define IDN_TN_NARROW_SPLITS 256
@@ -926,19 +1003,19 @@ static int device_cus(int* out) {
     static LaunchSetup st;
     return st.get([]() -> int { return IDN_OK; }, out);
 }
-template <int NTW, int KTW, int NB>
+template <int NTW, int KTW, int NB, int R = kTnRows>
 static int launch_tn(const TNArgs& g, dim3 grid, hipStream_t s) {
-    constexpr size_t lds = (size_t)NB * kTnRows * (size_t)(64 * NTW + 64 * KTW) * 4;
+    constexpr size_t lds = (size_t)NB * R * (size_t)(64 * NTW + 64 * KTW) * 4;
     static_assert(lds <= 160 * 1024, "the chunk ring must fit a CU's LDS");
     static LaunchSetup setup;
     int num_cu = 0;
     if (int e = setup.get([]() -> int {
-            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<NTW, KTW, NB>),
+            IDN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<NTW, KTW, NB, R>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             return IDN_OK;
         }, &num_cu))
         return e;
-    hipLaunchKernelGGL((gemm_tn_kernel<NTW, KTW, NB>), grid, dim3(256), lds, s, g);
+    hipLaunchKernelGGL((gemm_tn_kernel<NTW, KTW, NB, R>), grid, dim3(256), lds, s, g);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }
@@ -956,8 +1033,10 @@ static int run_tn_partials(X6Pending& x6, const float* A, int lda, int N, const 
     else if (N == 64 && K == 128) { ntw = 1; ktw = 2; }
     else return fail(IDN_EUNSUPPORTED, "gemm_tn: no instantiation for %d x %d", N, K);
     const int bx = N / (64 * ntw), by = K / (64 * ktw);
-    const long chunks = P / kTnRows;
     const bool narrow = ntw * ktw <= 4 && !(ntw == 2 && ktw == 2);     // <4,1>, <2,1>, <1,2>
+    const int rows_per_chunk = !narrow ? kTnRows : (ntw == 4 ? IDN_TN_ROWS_4x1 : IDN_TN_ROWS_THIN);
+    if (P % rows_per_chunk) return fail(IDN_EINVAL, "gemm_tn: %lld rows are not a multiple of the %d-row chunk", (long long)P, rows_per_chunk);
+    const long chunks = P / rows_per_chunk;
     int splits = (narrow ? IDN_TN_NARROW_SPLITS : kMaxSplits) / (bx * by);
     if (ntw == 4 && ktw == 4 && pipe == kPipeX6) {   // one product per workgroup: the CUs are divided among the pass's products
         int cus = 0;
@@ -990,11 +1069,11 @@ static int run_tn_partials(X6Pending& x6, const float* A, int lda, int N, const 
     ProfScope prof(s, P, IDN_PROF_DW_GEMM);
     int e;
     if (ntw == 4 && ktw == 4) e = launch_tn<4, 4, kTnBufs>(g, grid, s);
-    else if (ntw == 4 && ktw == 1) e = launch_tn<4, 1, IDN_TN_NARROW_BUFS>(g, grid, s);
+    else if (ntw == 4 && ktw == 1) e = launch_tn<4, 1, IDN_TN_NARROW_BUFS, IDN_TN_ROWS_4x1>(g, grid, s);
     else if (ntw == 2 && ktw == 4) e = launch_tn<2, 4, kTnBufs>(g, grid, s);
-    else if (ntw == 2 && ktw == 1) e = launch_tn<2, 1, IDN_TN_NARROW_BUFS>(g, grid, s);
+    else if (ntw == 2 && ktw == 1) e = launch_tn<2, 1, IDN_TN_NARROW_BUFS, IDN_TN_ROWS_THIN>(g, grid, s);
     else if (ntw == 2 && ktw == 2) e = launch_tn<2, 2, kTnBufs>(g, grid, s);
-    else e = launch_tn<1, 2, IDN_TN_NARROW_BUFS>(g, grid, s);
+    else e = launch_tn<1, 2, IDN_TN_NARROW_BUFS, IDN_TN_ROWS_THIN>(g, grid, s);
     if (e) return e;
     *splits_out = splits;
     return IDN_OK;
