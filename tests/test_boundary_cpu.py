@@ -48,11 +48,12 @@ def test_ctypes_structs_match_c_layout(idn, tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "idealnerf.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(idn_facenerf_params), '
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(idn_facenerf_params), '
         'sizeof(idn_composite_out), sizeof(idn_render_args), offsetof(idn_facenerf_params, dim_aud), '
         'offsetof(idn_render_args, t_vals), offsetof(idn_render_args, tap_inds), '
         'offsetof(idn_render_args, workspace_bytes), offsetof(idn_render_args, precision_fine_plus1), '
-        'sizeof(idn_frame), offsetof(idn_frame, focal), offsetof(idn_frame, rays_out));return 0;}\n')
+        'sizeof(idn_frame), offsetof(idn_frame, focal), offsetof(idn_frame, rays_out), sizeof(idn_audio_net_params), '
+        'offsetof(idn_audio_net_params, dim_aud), sizeof(idn_audio_net_grads));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
@@ -60,7 +61,8 @@ def test_ctypes_structs_match_c_layout(idn, tmp_path):
     want = [C.sizeof(L.FaceNerfParams), C.sizeof(L.CompositeOut), C.sizeof(L.RenderArgs),
             L.FaceNerfParams.dim_aud.offset, L.RenderArgs.t_vals.offset, L.RenderArgs.tap_inds.offset,
             L.RenderArgs.workspace_bytes.offset, L.RenderArgs.precision_fine_plus1.offset,
-            C.sizeof(L.Frame), L.Frame.focal.offset, L.Frame.rays_out.offset]
+            C.sizeof(L.Frame), L.Frame.focal.offset, L.Frame.rays_out.offset,
+            C.sizeof(L.AudioNetParams), L.AudioNetParams.dim_aud.offset, C.sizeof(L.AudioNetGrads)]
     assert got == want
 
 
@@ -75,6 +77,23 @@ def test_c_abi_argument_errors_without_gpu(idn):
     a.precision = 7
     assert lib.idealnerf_render_rays_fwd(C.byref(a), None) == -2  # IDN_EUNSUPPORTED
     assert lib.idealnerf_render_workspace_bytes(0, 64, 128) == 0
+    # AudioNet kernels: NULL parameters, a dim_aud the kernel is not built for and more windows than the backward holds in LDS
+    ap = idn._lib.AudioNetParams()
+    assert lib.idealnerf_audio_net_fwd(C.byref(ap), None, 1, None, None, None) == -1 and b"NULL" in lib.idealnerf_last_error()
+    for i in range(4):
+        ap.conv_w[i] = ap.conv_b[i] = 1
+    for i in range(2):
+        ap.fc_w[i] = ap.fc_b[i] = 1
+    ap.dim_aud = 500
+    assert lib.idealnerf_audio_net_fwd(C.byref(ap), 1, 1, 1, None, None) == -2 and b"dim_aud" in lib.idealnerf_last_error()
+    ap.dim_aud = 64
+    ag = idn._lib.AudioNetGrads()
+    for i in range(4):
+        ag.conv_w[i] = ag.conv_b[i] = 1
+    for i in range(2):
+        ag.fc_w[i] = ag.fc_b[i] = 1
+    assert lib.idealnerf_audio_net_bwd(C.byref(ap), C.byref(ag), 1, 1, 1, 9, None) == -2 and b"windows" in lib.idealnerf_last_error()
+    assert lib.idealnerf_audio_net_saved_floats(8) == 8 * 640 and lib.idealnerf_audio_net_fwd(C.byref(ap), None, 0, None, None, None) == 0
     # frame mode: the camera replaces the ray records -- a rays pointer, rows outside the frame or a ray count that is not
     # the band's are refused before any HIP call
     f = idn._lib.Frame()

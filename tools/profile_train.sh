@@ -15,7 +15,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA
   rocprofv3 --pmc $set --output-format csv -d $O/pmc_$tag -- $B > $O/pmc_$tag.log 2>&1
   echo "pmc $tag done"
 done
-for K in "gemm_tn_x6_kernel" "gemm_tn_kernel<4, 1>" "delta_chain_x6_kernel" "mlp_bf16x6_kernel<0, true>"; do
+for K in "gemm_tn_x6_kernel" "gemm_tn_kernel<4, 1," "delta_chain_x6_kernel" "mlp_bf16x6_kernel<0, true>"; do
   name=$(echo "$K" | tr -c 'a-zA-Z0-9' '_' | sed 's/__*/_/g; s/_$//')
   python3 tools/pmc_summary.py "$K" $O/pmc_$name.json $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_WAVE_CYCLES $O/pmc_GRBM_GUI_ACTIVE > $O/pmc_$name.log
 done
