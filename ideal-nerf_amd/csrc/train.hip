@@ -245,16 +245,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
         // unrolled, hipcc shuffles the 256 accumulator registers between steps (~500 v_accvgpr_mov per chunk)
         LdsVec<NTW> a0v, a1v;
         LdsVec<KTW> b0v, b1v;
-        auto mm = [&](const LdsVec<NTW>& av, const LdsVec<KTW>& bv) {
-#ifdef IDN_TN_TIMING_NO_MFMA     // timing-only experiment (wrong results): the data movement alone
-            acc[0][0][0] += av.get(0) * bv.get(0);
-            return;
-#endif
-#pragma unroll
-            for (int x = 0; x < NTW; ++x)
-#pragma unroll
-                for (int y = 0; y < KTW; ++y) acc[x][y] = mfma32(av.get(x), bv.get(y), acc[x][y]);
-        };
         constexpr int kStepA = 2 * BN * 4, kStepB = 2 * BK * 4;   // bytes from one point-pair to the next
         uint32_t pa = a_addr0 + buf * (kTileFloats * 4), pb = b_addr0 + buf * (kTileFloats * 4);
         a0v.template issue<0>(pa);
@@ -319,43 +309,63 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs g) {
                      [&]() {});
             }
         } else {
-#pragma unroll 1
-        for (int it = 0; it < kSteps / 4; ++it) {
+            // Two MFMAs per point pair (the 128 x 64 and 64 x 128 shapes): a pair is too short to hide anything behind, so a step
+            // is TWO pairs -- four MFMAs, the reads of the next two pairs behind the first two of them, the piece behind the third,
+            // pointer / column-sum work behind the fourth -- on four register sets.
+            static_assert(M == 2 && kSteps % 8 == 0, "the two-pair schedule");
+            LdsVec<NTW> a2v, a3v;
+            LdsVec<KTW> b2v, b3v;
             a1v.template issue<kStepA>(pa);
             b1v.template issue<kStepB>(pb);
-            if (more && 2 * it < NPA) piece_a(cnext, buf2, 2 * it);
-            lds_retire<2>(a0v, b0v);
-            if (colsum_block && it < R / 16) {   // batch `it` of the column reads was issued before a0v / b0v: it has landed too
-                tn_static_for<16>([&](auto Row) { csum += landed(cs[decltype(Row)::value]); });
+            auto quad = [&](LdsVec<NTW>& c0a, LdsVec<KTW>& c0b, LdsVec<NTW>& c1a, LdsVec<KTW>& c1b, LdsVec<NTW>& n0a, LdsVec<KTW>& n0b,
+                            LdsVec<NTW>& n1a, LdsVec<KTW>& n1b, bool last, auto&& side_c, auto&& side_d) {
+                lds_retire<0>(c0a, c0b);
+                lds_retire<0>(c1a, c1b);
+                // the two pairs after these; past the chunk's last pair the reads are repeated on the current rows (never used)
+                const uint32_t na = last ? pa : pa + 2 * kStepA, nb = last ? pb : pb + 2 * kStepB;
+                auto mf = [&](LdsVec<NTW>& ca, LdsVec<KTW>& cb, auto M_) {
+                    constexpr int m = decltype(M_)::value, x = m / KTW, y = m % KTW;
+                    acc[x][y] = mfma32(ca.get(x), cb.get(y), acc[x][y]);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                mf(c0a, c0b, ic_<0>{});
+                n0a.template issue<0>(na);
+                n0b.template issue<0>(nb);
+                __builtin_amdgcn_sched_barrier(0);
+                mf(c0a, c0b, ic_<1>{});
+                n1a.template issue<kStepA>(na);
+                n1b.template issue<kStepB>(nb);
+                __builtin_amdgcn_sched_barrier(0);
+                mf(c1a, c1b, ic_<0>{});
+                side_c();
+                __builtin_amdgcn_sched_barrier(0);
+                mf(c1a, c1b, ic_<1>{});
+                side_d();
+                pa = na;
+                pb = nb;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll 1
+            for (int it = 0; it < kSteps / 8; ++it) {
+                quad(a0v, b0v, a1v, b1v, a2v, b2v, a3v, b3v, false,
+                     [&]() { if (more && 2 * it < NPA) piece_a(cnext, buf2, 2 * it); },
+                     [&]() {
+                         if (colsum_block && it < R / 16) {   // batch `it` of the column reads is older than these operand reads: retired with them
+                             tn_static_for<16>([&](auto Row) { csum += landed(cs[decltype(Row)::value]); });
+                         }
+                     });
+                quad(a2v, b2v, a3v, b3v, a0v, b0v, a1v, b1v, false,
+                     [&]() { if (more && 2 * it + 1 < NPA) piece_a(cnext, buf2, 2 * it + 1); },
+                     [&]() { if (colsum_block && it + 1 < R / 16) cs_issue(it + 1); });
             }
-            mm(a0v, b0v);
-            pa += 2 * kStepA;
-            pb += 2 * kStepB;
-            if (colsum_block && it + 1 < R / 16) cs_issue(it + 1);
-            a0v.template issue<0>(pa);
-            b0v.template issue<0>(pb);
-            if (more && 2 * it + 1 < NPA) piece_a(cnext, buf2, 2 * it + 1);
-            lds_retire<2>(a1v, b1v);
-            mm(a1v, b1v);
-        }
 #pragma unroll 1
-        for (int it = 0; it < kSteps / 4; ++it) {
-            a1v.template issue<kStepA>(pa);
-            b1v.template issue<kStepB>(pb);
-            if (more && 2 * it < NPB) piece_b(cnext, buf2, 2 * it);
-            lds_retire<2>(a0v, b0v);
-            mm(a0v, b0v);
-            // the pair after next; past the last pair the read is repeated on the current rows (never used):
-            // one loop shape for all iterations keeps the accumulators where they are
-            const bool last = it == kSteps / 4 - 1;
-            pa = last ? pa : pa + 2 * kStepA;
-            pb = last ? pb : pb + 2 * kStepB;
-            a0v.template issue<0>(pa);
-            b0v.template issue<0>(pb);
-            if (more && 2 * it + 1 < NPB) piece_b(cnext, buf2, 2 * it + 1);
-            lds_retire<2>(a1v, b1v);
-            mm(a1v, b1v);
-        }
+            for (int it = 0; it < kSteps / 8; ++it) {
+                quad(a0v, b0v, a1v, b1v, a2v, b2v, a3v, b3v, false,
+                     [&]() { if (more && 2 * it < NPB) piece_b(cnext, buf2, 2 * it); }, [&]() {});
+                quad(a2v, b2v, a3v, b3v, a0v, b0v, a1v, b1v, it == kSteps / 8 - 1,
+                     [&]() { if (more && 2 * it + 1 < NPB) piece_b(cnext, buf2, 2 * it + 1); }, [&]() {});
+            }
+            lds_retire<0>(a1v, b1v);
         }
         lds_retire<0>(a0v, b0v);   // drain the repeated read before these registers are reused
         buf = buf + 1 == NB ? 0 : buf + 1;
