@@ -456,6 +456,31 @@ def test_obama_configs_render_by_name(idn, dev, cfg_name):
     assert rel_err(extras["rgb0"], ref["rgb0"]) < RGB_TOL
 
 
+def test_network_under_dataparallel_like_the_eval_script(idn, dev):
+    """The reference's eval script wraps the renderer in `nn.DataParallel` (test/eval_aud_exp_nerf.py:475; batch dimension 1, so
+    one device does the work) and calls `network([data, global_step, dataset_size])` with the loader's CPU tensors: scatter moves
+    them to the device, the module runs once.  The wrapped call must give the direct call's frame bit for bit."""
+    from idealnerf_amd.audio_exp_nerf import Network
+    from idealnerf_amd.helper import RenderConfig
+    dims = oracle.facenerf_dims()
+    syn = oracle.synthetic_frame(24, 24, seed=2, dims=dims)
+    torch.manual_seed(5)
+    net = Network(24, 24, syn["focal"], NEAR, FAR, 8192, None, 64, 128, args=RenderConfig(perturb=0.0, near=NEAR, far=FAR)).to(dev).eval()
+    net.face_nerf_coarse.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(41, dims)))
+    net.face_nerf_fine.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(42, dims)))
+    auds = torch.randn(1, 8, 16, 29)
+    pose = torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)[None]
+    data = (torch.zeros(1, 2, 1, 3), torch.zeros(1, 3), syn["bc"][None], auds, torch.zeros(1, 24, 24, 3), pose, syn["expr"][None],
+            syn["latent"], torch.tensor([3]))
+    with torch.no_grad():
+        direct = net([data, 0, 8])
+        wrapped = torch.nn.DataParallel(net, device_ids=[dev.index or 0])([data, 0, 8])
+    assert direct[0].shape == (24, 24, 3) and float((direct[0] - syn["bc"].to(dev)).abs().mean()) > 0.02
+    for a, b in zip(direct[:4], wrapped[:4]):
+        assert torch.equal(a, b)
+    assert set(direct[4]) == set(wrapped[4]) and all(torch.equal(direct[4][k], wrapped[4][k]) for k in direct[4])
+
+
 # --------------------------------------------------------------------------- SURVEY 8(f)1: checkpoints on the GPU path
 def _render_vs_oracle_on_its_state_dict(idn, dev, net, latent, what, n_rays=256, seed=5):
     """`n_rays` rays of a 32 x 32 frame through `net` (whatever weights it holds NOW), held to the CPU oracle evaluated on
