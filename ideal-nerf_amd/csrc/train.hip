@@ -548,16 +548,32 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    // The fragments of a chunk's FIRST tile row (fa[0], fb[0], fb[1]: nine reads) are issued one chunk EARLY: the chunk barrier
+    // sits behind MFMA 59 of the 72 of rows 1..3 -- by then this wave's pieces of the next chunk are stored (slices end at MFMA
+    // 51) and fa[0] / fb[0] / fb[1] have had their last use -- so the next chunk's first reads run under the last twelve MFMAs
+    // instead of behind a barrier with nothing to overlap (IDN_X6_EARLY_BARRIER=0: the barrier at the end of the chunk).
+#ifndef IDN_X6_EARLY_BARRIER
+#define IDN_X6_EARLY_BARRIER 1
+#endif
+    X6Frag fa[4][3], fb[4][3];
+    auto issue_first_row = [&](uint32_t pa, uint32_t pb) {
+        tn_static_for<3>([&](auto Q) { fa[0][decltype(Q)::value].template issue<decltype(Q)::value * kFragBytes>(pa); });
+        tn_static_for<2>([&](auto Y) {
+            tn_static_for<3>([&](auto Q) {
+                fb[decltype(Y)::value][decltype(Q)::value].template issue<(decltype(Y)::value * 3 + decltype(Q)::value) * kFragBytes>(pb);
+            });
+        });
+    };
+    if (IDN_X6_EARLY_BARRIER) issue_first_row(a_base, b_base);
 #pragma unroll 1
     for (int rc = 0; rc < n_chunks; ++rc) {
         const int buf = rc & 1;
         const uint32_t pa = a_base + buf * kX6BufBytes, pb = b_base + buf * kX6BufBytes;
-        X6Frag fa[4][3], fb[4][3];
-        // issue order = consumption order of row 0, then the other delta tiles
-        tn_static_for<3>([&](auto Q) { fa[0][decltype(Q)::value].template issue<decltype(Q)::value * kFragBytes>(pa); });
-        tn_static_for<4>([&](auto Y) {
+        // issue order = consumption order: row 0 (nine of its reads are already in flight), then the other delta tiles
+        if (!IDN_X6_EARLY_BARRIER) issue_first_row(pa, pb);
+        tn_static_for<2>([&](auto Y) {
             tn_static_for<3>([&](auto Q) {
-                fb[decltype(Y)::value][decltype(Q)::value].template issue<(decltype(Y)::value * 3 + decltype(Q)::value) * kFragBytes>(pb);
+                fb[decltype(Y)::value + 2][decltype(Q)::value].template issue<((decltype(Y)::value + 2) * 3 + decltype(Q)::value) * kFragBytes>(pb);
             });
         });
         tn_static_for<3>([&](auto X) {
@@ -641,14 +657,30 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
             constexpr int qa = t == 2 || t == 3 ? 1 : (t == 5 ? 2 : 0);   // a1 b1, a1 b2, a2 b1, a2 b2, a1 b3, a3 b1
             constexpr int qb = t == 1 || t == 3 ? 1 : (t == 4 ? 2 : 0);
             acc[x][y] = mfma_bf16(fa[x][qa].v, fb[y][qb].v, acc[x][y]);
-            if constexpr (k < 36) slice(ic_<0>{}, ic_<k>{});
-            else slice(ic_<1>{}, ic_<k - 36>{});
+            constexpr int kX1 = IDN_X6_EARLY_BARRIER ? 26 : 36;     // where the activation matrix's slices start (each matrix has 26)
+            if constexpr (k < kX1) slice(ic_<0>{}, ic_<k>{});
+            else slice(ic_<1>{}, ic_<k - kX1>{});
+            if constexpr (IDN_X6_EARLY_BARRIER && k == 59) {
+                // everyone's pieces of chunk rc + 1 are in LDS; everyone has read chunk rc's (all 24 fragment reads were retired
+                // before row 1): the chunk barrier, twelve MFMAs early, and behind it the first row of the next chunk
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_first_row(a_base + (buf ^ 1) * kX6BufBytes, b_base + (buf ^ 1) * kX6BufBytes);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // everyone's pieces of chunk rc + 1 are in LDS; everyone has read chunk rc's
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if (!IDN_X6_EARLY_BARRIER) {
+            // everyone's pieces of chunk rc + 1 are in LDS; everyone has read chunk rc's
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    if (IDN_X6_EARLY_BARRIER) {   // the first-row reads issued behind the last chunk's barrier (of a chunk that does not exist): retired, never used
+        x6_retire<0>(fa[0]);
+        x6_retire<0>(fb[0]);
+        x6_retire<0>(fb[1]);
     }
     // the clamped re-reads of the last chunk are still in flight into ra / rb: retired here, so that the next item of a batch
     // starts on registers nothing is about to write (the stores below then drain under that item's first loads)
