@@ -489,10 +489,8 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
     // reload got a fresh register and a copy at the loop end -- behind a wait for the load, a chunk early.  vmcnt is
     // therefore counted by hand: loads are issued in ONE order (delta rows 0..15, activation rows 0..15) everywhere,
     // so when pair j is split, exactly 30 loads are younger than its second row.
-    // (What bounds this kernel is how much it keeps in flight: one chunk per workgroup = 8 MB chip-wide over a ~2.2 us chunk is
-    // 3.6 TB/s, the rate it runs at; with cache-hot reloads -- -DIDN_X6_TIMING_SAME_ROWS -- it is 8 % faster.  A second register
-    // set per matrix -- two chunks in flight, vmcnt(62) -- was built in round 4: 238 architectural VGPRs besides the 256
-    // accumulators do not fit, hipcc spilled 164 registers, among them rows whose loads were in flight; the audit rejected it.)
+    // (With cache-hot reloads -- -DIDN_X6_TIMING_SAME_ROWS -- the kernel is 8 % faster; a second register set per matrix -- two
+    // chunks in flight, vmcnt(62) -- was built and measured in round 4: no gain, so it is not the prefetch depth.  profiles/HISTORY.md)
     auto make_rsrc = [](const float* ptr) {
         const uint64_t a64 = (uint64_t)(uintptr_t)ptr;
         return tn_i32x4{(int)(uint32_t)a64, (int)((uint32_t)(a64 >> 32) & 0xffffu), (int)0xfffffffcu, 0x00020000};
