@@ -25,7 +25,9 @@ uses without importing it) is put into its namespace, and ``NeRFs.TorsoNeRF.trai
 once ``get_embedder``'s default device is 'cpu' instead of 'cuda' (it only places the
 frequency table) -- ``python make_golden.py headtorso``.  ``python make_golden.py frame512``
 renders the first 4096 rays of the 512x512 bench frame (BASELINE configs[1]) with the
-reference's ``Network.render_rays``.
+reference's ``Network.render_rays``.  ``python make_golden.py smoother`` / ``ds29`` run the reference's
+``Network.forward`` itself on a 12 x 12 frame: behind ``nosmo_iters`` (the eight-frame audio window with its padding,
+AudioNet + AudioAttNet) and in the ``dim_aud = 29`` configuration (``ds_aud_net``, FaceNeRFs with 29 audio columns).
 """
 import argparse
 import os
@@ -744,6 +746,113 @@ def golden_head_torso():
           f"{os.path.getsize(os.path.join(HERE, 'head_torso.npz')) / 1024:.0f} KiB")
 
 
+def golden_smoother():
+    """`python make_golden.py smoother`: the reference's `Network.forward` (audio_exp_nerf.py:228-279) BEHIND `nosmo_iters` --
+    the window of `smo_size` = 8 DeepSpeech frames around `index`, zero-padded at the clip's ends (:246-262), AudioNet on the
+    window and AudioAttNet on its output -- in eval mode on a 12 x 12 frame of a 10-frame clip, for a frame at the clip's
+    start (three padded slots on the left), one in the middle and one at its end (two on the right).  Stored: the inputs,
+    the two audio nets' weights (they are drawn from torch's generator upstream), and per frame the audio feature the
+    reference hands to its renderer (captured at `render_dynamic_face`) and the rendered frame."""
+    install_shims()
+    sys.argv = [sys.argv[0], "--perturb", "0", "--dim_aud", "64", "--dim_expr", "76",
+                "--N_samples", "64", "--N_importance", "128", "--near", str(NEAR), "--far", str(FAR),
+                "--vis_path", "/tmp/idealnerf_golden_vis", "--chunk", "512"]
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    import oracle
+    from NeRFs.HeadNeRF.train import audio_exp_nerf as aen
+    dims = oracle.facenerf_dims()
+    H = W = 12
+    F_ = 10
+    syn = oracle.synthetic_frame(H, W, seed=9, dims=dims)
+    net = aen.Network(H, W, syn["focal"], NEAR, FAR, 512, None, 64, 128)
+    net.apply(aen.init_weights)
+    load_state(net.face_nerf_coarse, scale_sigma(oracle.xavier_facenerf_params(2, dims), 300.0, 0.3))
+    load_state(net.face_nerf_fine, scale_sigma(oracle.xavier_facenerf_params(3, dims), 300.0, 0.3))
+    net.eval()
+    rs = np.random.RandomState(77)
+    auds = torch.from_numpy(rs.standard_normal((F_, 16, 29)).astype(np.float32))
+    pose = torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
+    fx = dict(auds=auds.numpy(), pose=pose.numpy(), bg=syn["bc"].numpy(), expr=syn["expr"].numpy(), latent=syn["latent"].numpy(),
+              focal=np.float64(syn["focal"]), nosmo_iters=np.int64(aen.args.nosmo_iters), frames=np.array([1, 5, 8]))
+    for k, v in net.aud_net.state_dict().items():
+        fx["audnet." + k] = v.numpy()
+    for k, v in net.aud_att_net.state_dict().items():
+        fx["attnet." + k] = v.numpy()
+    real_rdf = net.render_dynamic_face
+    for idx in (1, 5, 8):
+        seen = {}
+
+        def spy(*a, **k):
+            seen["aud"] = k["aud_para"].detach().clone()
+            return real_rdf(*a, **k)
+
+        net.render_dynamic_face = spy
+        data = (torch.zeros(1, 2, 1, 3), torch.zeros(1, 3), syn["bc"][None], auds[None], torch.zeros(1, H, W, 3), pose[None],
+                syn["expr"][None], syn["latent"], torch.tensor([idx]))
+        with torch.no_grad():
+            rgb, disp, acc, last_w, extras = net([data, int(aen.args.nosmo_iters), F_])
+        fx[f"aud_feature_{idx}"] = seen["aud"].numpy()
+        fx[f"rgb_{idx}"] = rgb.numpy()
+        fx[f"rgb0_{idx}"] = extras["rgb0"].numpy()
+    net.render_dynamic_face = real_rdf
+    assert fx["aud_feature_1"].shape == (64,) and not np.allclose(fx["aud_feature_1"], fx["aud_feature_5"])
+    vis = float(np.abs(fx["rgb_5"] - syn["bc"].numpy()).mean())
+    np.savez_compressed(os.path.join(HERE, "smoother.npz"), **fx)
+    print(f"wrote smoother.npz: frames 1, 5, 8 of a {F_}-frame clip, {H}x{W}, visibility {vis:.3f}, "
+          f"{os.path.getsize(os.path.join(HERE, 'smoother.npz')) / 1024:.0f} KiB")
+
+
+def golden_ds29():
+    """`python make_golden.py ds29`: the reference's `Network.forward` in its `dim_aud = 29` configuration (the DeepSpeech-logit
+    ablation: `*_adnerf_baseline`-style configs; audio_exp_nerf.py:265-269 takes `ds_aud_net`, a Linear(16, 1) squeeze over
+    the window, instead of AudioNet, and the FaceNeRFs are built with 29 audio columns: C = 63 + 29 + 76 + 32 = 200) in eval
+    mode on a 12 x 12 frame.  Stored: inputs, `ds_aud_net`'s weights, the audio feature handed to the renderer, the frame."""
+    install_shims()
+    sys.argv = [sys.argv[0], "--perturb", "0", "--dim_aud", "29", "--dim_expr", "76",
+                "--N_samples", "64", "--N_importance", "128", "--near", str(NEAR), "--far", str(FAR),
+                "--vis_path", "/tmp/idealnerf_golden_vis", "--chunk", "512"]
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    import oracle
+    from NeRFs.HeadNeRF.train import audio_exp_nerf as aen
+    dims = oracle.facenerf_dims(dim_aud=29)
+    H = W = 12
+    syn = oracle.synthetic_frame(H, W, seed=9, dims=dims)
+    net = aen.Network(H, W, syn["focal"], NEAR, FAR, 512, None, 64, 128)
+    net.apply(aen.init_weights)
+    load_state(net.face_nerf_coarse, scale_sigma(oracle.xavier_facenerf_params(2, dims), 300.0, 0.3))
+    load_state(net.face_nerf_fine, scale_sigma(oracle.xavier_facenerf_params(3, dims), 300.0, 0.3))
+    net.eval()
+    rs = np.random.RandomState(78)
+    auds = torch.from_numpy(rs.standard_normal((6, 16, 29)).astype(np.float32))
+    pose = torch.cat([syn["c2w"], torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
+    fx = dict(auds=auds.numpy(), pose=pose.numpy(), bg=syn["bc"].numpy(), expr=syn["expr"].numpy(), latent=syn["latent"].numpy(),
+              focal=np.float64(syn["focal"]), index=np.int64(4))
+    for k, v in net.ds_aud_net.state_dict().items():
+        fx["dsnet." + k] = v.numpy()
+    real_rdf, seen = net.render_dynamic_face, {}
+
+    def spy(*a, **k):
+        seen["aud"] = k["aud_para"].detach().clone()
+        return real_rdf(*a, **k)
+
+    net.render_dynamic_face = spy
+    data = (torch.zeros(1, 2, 1, 3), torch.zeros(1, 3), syn["bc"][None], auds[None], torch.zeros(1, H, W, 3), pose[None],
+            syn["expr"][None], syn["latent"], torch.tensor([4]))
+    with torch.no_grad():
+        rgb, disp, acc, last_w, extras = net([data, 0, 6])
+    assert seen["aud"].shape == (29,) and tuple(net.face_nerf_coarse.pts_linears[0].weight.shape) == (256, 200)
+    fx.update(aud_feature=seen["aud"].numpy(), rgb=rgb.numpy(), rgb0=extras["rgb0"].numpy(), last_weight=last_w.numpy())
+    vis = float(np.abs(fx["rgb"] - syn["bc"].numpy()).mean())
+    np.savez_compressed(os.path.join(HERE, "ds29.npz"), **fx)
+    print(f"wrote ds29.npz: {H}x{W}, visibility {vis:.3f}, {os.path.getsize(os.path.join(HERE, 'ds29.npz')) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "flags":
         golden_flags()
@@ -755,5 +864,9 @@ if __name__ == "__main__":
         golden_agg()
     elif len(sys.argv) > 1 and sys.argv[1] == "torso":
         golden_torso()
+    elif len(sys.argv) > 1 and sys.argv[1] == "smoother":
+        golden_smoother()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ds29":
+        golden_ds29()
     else:
         main()

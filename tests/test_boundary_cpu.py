@@ -399,6 +399,44 @@ def test_fused_arrangement_flag_is_validated(idn):
     assert r.returncode == 0 and r.stdout.strip() == "2", r.stderr
 
 
+def _smoother_network(idn, g, dev):
+    from idealnerf_amd.audio_exp_nerf import Network
+    from idealnerf_amd.helper import RenderConfig
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    net = Network(12, 12, float(g["focal"]), 0.5772005200386048, 1.1772005200386046, 512, None, 64, 128,
+                  args=RenderConfig(perturb=0.0, chunk=512, near=0.5772005200386048, far=1.1772005200386046))
+    net.aud_net.load_state_dict({k[len("audnet."):]: T(v) for k, v in g.items() if k.startswith("audnet.")})
+    net.aud_att_net.load_state_dict({k[len("attnet."):]: T(v) for k, v in g.items() if k.startswith("attnet.")})
+    return net.to(dev).eval()
+
+
+def _smoother_data(g, idx):
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    return (torch.zeros(1, 2, 1, 3), torch.zeros(1, 3), T(g["bg"])[None], T(g["auds"])[None], torch.zeros(1, 12, 12, 3), T(g["pose"])[None],
+            T(g["expr"])[None], T(g["latent"]), torch.tensor([idx]))
+
+
+def test_forward_smoother_window_matches_the_reference(idn):
+    """`Network.forward` behind `nosmo_iters` (audio_exp_nerf.py:235-264): the window of eight DeepSpeech frames around `index`,
+    zero-padded at the clip's ends, AudioNet on the window, AudioAttNet on its output.  Golden = the reference's own forward
+    (tests/golden/smoother.npz: the audio feature it hands to its renderer for a frame at the start, in the middle and at the
+    end of a 10-frame clip); here on the CPU with the renderer stubbed out -- the render itself is held to the same fixture in -m gpu."""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "smoother.npz")))
+    net = _smoother_network(idn, g, "cpu")
+    seen = {}
+    net.render_dynamic_face = lambda *a, **k: seen.update(aud=k["aud_para"].detach().clone(), expr=k["expr"]) or [None] * 5
+    for idx in g["frames"]:
+        with torch.no_grad():
+            net([_smoother_data(g, int(idx)), int(g["nosmo_iters"]), 10])
+        np.testing.assert_allclose(seen["aud"].numpy(), g[f"aud_feature_{int(idx)}"], rtol=1e-5, atol=1e-6, err_msg=f"frame {idx}")
+        assert seen["expr"].shape == (76,)
+    # one step before the switch the feature is AudioNet's of the frame's own window
+    with torch.no_grad():
+        net([_smoother_data(g, 5), int(g["nosmo_iters"]) - 1, 10])
+        own = net.aud_net(torch.from_numpy(g["auds"])[5:6])
+    assert torch.allclose(seen["aud"], own) and not np.allclose(own.numpy(), g["aud_feature_5"], atol=1e-3)
+
+
 @pytest.fixture
 def process_flags():
     """Tests that parse flags into the process-wide slot leave it, sys.argv and helper.args as they found them."""

@@ -456,6 +456,68 @@ def test_obama_configs_render_by_name(idn, dev, cfg_name):
     assert rel_err(extras["rgb0"], ref["rgb0"]) < RGB_TOL
 
 
+def test_forward_smoother_golden(idn, dev, golden):
+    """The reference's `Network.forward` behind `nosmo_iters` (audio_exp_nerf.py:228-279; tests/golden/smoother.npz): eight-frame
+    audio window with zero padding at the clip's ends -> AudioNet (one HIP kernel for the eight windows) -> AudioAttNet ->
+    full-frame render.  The audio feature handed to the renderer and the rendered 12 x 12 frame against the reference's, for a
+    frame at the start, in the middle and at the end of the clip."""
+    from test_boundary_cpu import _smoother_data, _smoother_network
+    g = golden("smoother")
+    net = _smoother_network(idn, g, dev)
+    dims = oracle.facenerf_dims()
+    net.face_nerf_coarse.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(2, dims), 300.0, 0.3))
+    net.face_nerf_fine.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(3, dims), 300.0, 0.3))
+    real = net.render_dynamic_face
+    seen = {}
+
+    def spy(*a, **k):
+        seen["aud"] = k["aud_para"].detach().clone()
+        return real(*a, **k)
+
+    net.render_dynamic_face = spy
+    for idx in g["frames"]:
+        with torch.no_grad():
+            rgb, disp, acc, last_w, extras = net([_smoother_data(g, int(idx)), int(g["nosmo_iters"]), 10])
+        np.testing.assert_allclose(seen["aud"].cpu().numpy(), g[f"aud_feature_{int(idx)}"], rtol=2e-5, atol=2e-6, err_msg=f"frame {idx}")
+        assert rgb.shape == (12, 12, 3)
+        assert rel_err(extras["rgb0"], g[f"rgb0_{int(idx)}"]) < RGB_TOL, idx     # nothing is sampled before the coarse composite
+        e = np.abs(rgb.cpu().numpy().astype(np.float64) - g[f"rgb_{int(idx)}"]).reshape(-1, 3).max(1) / np.abs(g[f"rgb_{int(idx)}"]).max()
+        print(f"\n  smoother frame {int(idx)}: rgb vs the reference max {e.max():.2e}, {int((e > RGB_TOL).sum())} of {e.size} rays beyond 1e-4")
+        assert e.max() < 1e-3 and (e > RGB_TOL).sum() <= 3     # (the end-to-end guards of tests/parity_proof.py; measured: 0 rays)
+
+
+def test_forward_dim_aud_29_golden(idn, dev, golden):
+    """The reference's `dim_aud = 29` configuration (audio_exp_nerf.py:265-269: `ds_aud_net`, a Linear(16, 1) squeeze of the
+    DeepSpeech window, instead of AudioNet; FaceNeRFs with 29 audio columns, C = 200) through `Network.forward` in eval mode:
+    tests/golden/ds29.npz is the reference's own forward on a 12 x 12 frame.  A fourth conditioning layout of the same kernels."""
+    from idealnerf_amd.audio_exp_nerf import Network
+    from idealnerf_amd.helper import RenderConfig
+    g = golden("ds29")
+    net = Network(12, 12, float(g["focal"]), NEAR, FAR, 512, None, 64, 128,
+                  args=RenderConfig(perturb=0.0, chunk=512, near=NEAR, far=FAR, dim_aud=29)).to(dev).eval()
+    assert tuple(net.face_nerf_coarse.pts_linears[0].weight.shape) == (256, 200)
+    dims = oracle.facenerf_dims(dim_aud=29)
+    net.face_nerf_coarse.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(2, dims), 300.0, 0.3))
+    net.face_nerf_fine.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(3, dims), 300.0, 0.3))
+    net.ds_aud_net.load_state_dict({k[len("dsnet."):]: T(v).to(dev) for k, v in g.items() if k.startswith("dsnet.")})
+    real, seen = net.render_dynamic_face, {}
+
+    def spy(*a, **k):
+        seen["aud"] = k["aud_para"].detach().clone()
+        return real(*a, **k)
+
+    net.render_dynamic_face = spy
+    data = (torch.zeros(1, 2, 1, 3), torch.zeros(1, 3), T(g["bg"])[None], T(g["auds"])[None], torch.zeros(1, 12, 12, 3), T(g["pose"])[None],
+            T(g["expr"])[None], T(g["latent"]), torch.tensor([int(g["index"])]))
+    with torch.no_grad():
+        rgb, disp, acc, last_w, extras = net([data, 0, 6])
+    np.testing.assert_allclose(seen["aud"].cpu().numpy(), g["aud_feature"], rtol=1e-5, atol=1e-6)
+    assert rel_err(extras["rgb0"], g["rgb0"]) < RGB_TOL
+    e = np.abs(rgb.cpu().numpy().astype(np.float64) - g["rgb"]).reshape(-1, 3).max(1) / np.abs(g["rgb"]).max()
+    print(f"\n  dim_aud 29: rgb vs the reference max {e.max():.2e}, {int((e > RGB_TOL).sum())} of {e.size} rays beyond 1e-4")
+    assert e.max() < 1e-3 and (e > RGB_TOL).sum() <= 3
+
+
 def test_network_under_dataparallel_like_the_eval_script(idn, dev):
     """The reference's eval script wraps the renderer in `nn.DataParallel` (test/eval_aud_exp_nerf.py:475; batch dimension 1, so
     one device does the work) and calls `network([data, global_step, dataset_size])` with the loader's CPU tensors: scatter moves
