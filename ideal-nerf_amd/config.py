@@ -206,7 +206,9 @@ def current_args(kind: str = "head", parse_argv: bool = True):
     its modules are imported -- the command line, if it names a `--config`; else None."""
     ns = _current.get(kind)
     if ns is None and parse_argv and any(a == "--config" or a.startswith("--config=") for a in sys.argv[1:]):
-        ns = ConfigParser(kind).parse_args()
+        # (implicit path: flags this parser does not know -- the caller's own, or stale keys of the file -- are ignored here;
+        #  `config_parser().parse_args()` and `helper.args` stay as strict as upstream's parser and end the run on them)
+        ns, _ = ConfigParser(kind).parse_known_args()
     return ns
 
 

@@ -495,7 +495,7 @@ def test_unchanged_caller_gets_its_config(idn, tmp_path, process_flags):
     sys.argv[:] = ["pytest"]
     assert Network(32, 32, 100., 0.3, 0.9, 512, None, 64, 128).args.dim_expr == 76
     # ... and with --config on the command line but no parse_args() call, the command line is parsed as upstream does on import
-    sys.argv[:] = ["eval.py", "--config", str(cfg)]
+    sys.argv[:] = ["eval.py", "--config", str(cfg), "--my_own_flag", "7"]     # (a flag of the caller's own does not break the implicit path)
     assert Network(32, 32, 100., 0.3, 0.9, 512, None, 64, 128).args.dim_expr == 79
 
 
