@@ -534,13 +534,13 @@ def network_api_measurement(args, syn, coarse, fine, c_abi_value, c_abi_tile, fr
                                           bc_rgb=syn["bc"].to(dev), aud_para=syn["aud"].to(dev))[0]
     v = H * W * 256 / dt
     if perturb > 0.:
-        # the reference's DEFAULT eval mode (helper.py:70: --perturb 1.0): stratified depths and random u, drawn per chunk as
-        # upstream draws them, so batchify_rays keeps its chunk loop: 32 C calls, 64 folds and 64 torch.rand draws per frame
+        # the reference's DEFAULT eval mode (helper.py:70: --perturb 1.0): stratified depths and random u, drawn for the whole
+        # frame at once (round 3 drew them chunk by chunk: 32 C calls, 64 folds and 64 torch.rand draws per frame)
         return {"value": v, "unit": "ray-samples/s", "ms_per_frame": dt * 1e3, "ratio_to_c_abi": v / c_abi_value, "perturb": perturb,
-                "chunks_per_frame": (H * W + 8191) // 8192, "finite": bool(torch.isfinite(rgb).all()),
+                "finite": bool(torch.isfinite(rgb).all()),
                 "psnr_vs_deterministic_frame_db": float(-10.0 * torch.log10(((rgb.reshape(-1, 3).double() - c_abi_tile.reshape(-1, 3).double()) ** 2).mean().clamp_min(1e-30))),
-                "call": "Network.forward([data, global_step, dataset_size]) in eval mode with the reference's default perturb = 1.0 and "
-                        "chunk = 8192: t_rand and u drawn per chunk (torch.rand on the device), one C call per chunk"}
+                "call": "Network.forward([data, global_step, dataset_size]) in eval mode with the reference's default perturb = 1.0: "
+                        "t_rand and u of the whole frame drawn at once (torch.rand on the device), one C call per frame"}
     return {"value": v, "unit": "ray-samples/s", "ms_per_frame": dt * 1e3, "ratio_to_c_abi": v / c_abi_value,
             "identical_to_c_abi_frame": bool(torch.equal(net_rgb.reshape(-1, 3), c_abi_tile.reshape(-1, 3))),
             "call": "Network.forward([data, global_step, dataset_size]) in eval mode, chunk=8192, AudioNet + both folds per "

@@ -101,19 +101,21 @@ class Network(nn.Module):
         """Same results as the reference's chunk loop.  The loop exists upstream to bound the activation
         memory of a chunk (25 KB per sample); here activations never leave registers and the C call walks
         the rays in its own 32 768-ray passes over a fixed workspace, so a deterministic render
-        (perturb == 0: rays are independent and nothing is drawn per chunk) is ONE call whatever `chunk`
-        is -- one conditioning fold and one set of output tensors per frame instead of one per chunk.
-        With perturb > 0 the per-chunk random draws are part of the result (under `pytest` every chunk
-        re-seeds numpy, audio_exp_nerf.py:316-318), so the loop is kept."""
+        is ONE call whatever `chunk` is -- one conditioning fold and one set of output tensors per frame
+        instead of one per chunk.  With perturb > 0 (the reference's DEFAULT, also in eval: helper.py:70) the
+        stratified offsets and the importance draws of the whole frame are drawn at once, from the same generator and
+        the same distribution as upstream's per-chunk `torch.rand` calls (which chunk a draw lands in is not a
+        contract: upstream's CUDA generator gives other numbers than this device's anyway).  Only training keeps the
+        chunk loop (an autograd graph per chunk, as upstream)."""
         return self._batchify(rays, bc_rgb, aud_para, latent_code, expr, self.face_nerf_coarse, self.face_nerf_fine,
                               False, chunk)
 
     def _batchify(self, rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg, chunk, frame=None):
         training = torch.is_grad_enabled() and self.training
-        if not training and self.args.perturb == 0.:
+        if not training:
             # `frame`: a full frame's row band with the rays still to be derived -- on the device, inside the one C call
             return self._render(rays, bc_rgb, aud_para, latent_code, expr, coarse, fine, with_fg, frame=frame)
-        if frame is not None:   # the chunk loop slices ray records: materialise them (perturb > 0 draws per chunk)
+        if frame is not None:   # the chunk loop slices ray records: materialise them
             rays = ops.frame_rays(torch.tensor(list(frame.c2w)).reshape(3, 4), frame.H, frame.W, frame.focal, frame.near_, frame.far_,
                                   frame.row0, frame.nrows, None if frame.cx < 0 else frame.cx, None if frame.cy < 0 else frame.cy,
                                   device=bc_rgb.device)
