@@ -533,6 +533,23 @@ def network_api_measurement(args, syn, coarse, fine, c_abi_value, c_abi_tile, fr
                                           render_poses=pose[:3, :4], chunk=8192, near=syn["near"], far=syn["far"],
                                           bc_rgb=syn["bc"].to(dev), aud_para=syn["aud"].to(dev))[0]
     v = H * W * 256 / dt
+    in_kernel = None
+    if perturb > 0.:   # the same call with the draws made inside the kernels (idn_render_args.rng_mode; opt-in: net.in_kernel_draws)
+        net.in_kernel_draws = True
+        with torch.no_grad():
+            net([data, 0, 8])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                rgb_k = net([data, 0, 8])[0]
+            torch.cuda.synchronize()
+        dt_k = (time.perf_counter() - t0) / frames
+        net.in_kernel_draws = False
+        in_kernel = {"value": H * W * 256 / dt_k, "ms_per_frame": dt_k * 1e3, "ratio_to_c_abi": H * W * 256 / dt_k / c_abi_value,
+                     "finite": bool(torch.isfinite(rgb_k).all()),
+                     "psnr_vs_deterministic_frame_db": float(-10.0 * torch.log10(((rgb_k.reshape(-1, 3).double() - c_abi_tile.reshape(-1, 3).double()) ** 2).mean().clamp_min(1e-30))),
+                     "note": "net.in_kernel_draws = True: stratified offsets and importance draws from Philox4x32-10 inside the coarse-depth "
+                             "and march kernels (one seed per call from torch's CPU generator); no [n, S] / [n, Ni] random tensors"}
     if perturb > 0.:
         # the reference's DEFAULT eval mode (helper.py:70: --perturb 1.0): stratified depths and random u, drawn for the whole
         # frame at once (round 3 drew them chunk by chunk: 32 C calls, 64 folds and 64 torch.rand draws per frame)
@@ -540,7 +557,8 @@ def network_api_measurement(args, syn, coarse, fine, c_abi_value, c_abi_tile, fr
                 "finite": bool(torch.isfinite(rgb).all()),
                 "psnr_vs_deterministic_frame_db": float(-10.0 * torch.log10(((rgb.reshape(-1, 3).double() - c_abi_tile.reshape(-1, 3).double()) ** 2).mean().clamp_min(1e-30))),
                 "call": "Network.forward([data, global_step, dataset_size]) in eval mode with the reference's default perturb = 1.0: "
-                        "t_rand and u of the whole frame drawn at once (torch.rand on the device), one C call per frame"}
+                        "t_rand and u of the whole frame drawn at once (torch.rand on the device), one C call per frame",
+                "in_kernel_draws": in_kernel}
     return {"value": v, "unit": "ray-samples/s", "ms_per_frame": dt * 1e3, "ratio_to_c_abi": v / c_abi_value,
             "identical_to_c_abi_frame": bool(torch.equal(net_rgb.reshape(-1, 3), c_abi_tile.reshape(-1, 3))),
             "call": "Network.forward([data, global_step, dataset_size]) in eval mode, chunk=8192, AudioNet + both folds per "

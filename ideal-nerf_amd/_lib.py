@@ -43,7 +43,8 @@ class RenderArgs(C.Structure):
                                   "tap_z_coarse", "tap_raw_coarse", "tap_weights_coarse", "tap_cdf", "tap_inds",
                                   "tap_z_samples", "tap_z_fine", "tap_raw_fine", "tap_weights_fine")] + \
                [("workspace", fp), ("workspace_bytes", C.c_size_t), ("precision_fine_plus1", C.c_int),
-                ("lindisp", C.c_int), ("white_bkgd", C.c_int), ("noise_coarse", fp), ("noise_fine", fp), ("fused_march", C.c_int)]
+                ("lindisp", C.c_int), ("white_bkgd", C.c_int), ("noise_coarse", fp), ("noise_fine", fp), ("fused_march", C.c_int),
+                ("rng_mode", C.c_int), ("rng_seed", C.c_uint64), ("rng_ray0", C.c_int64)]
 
 
 class AudioNetParams(C.Structure):
@@ -59,7 +60,7 @@ class Frame(C.Structure):
                 ("near_", C.c_float), ("far_", C.c_float), ("row0", C.c_int), ("nrows", C.c_int), ("rays_out", fp)]
 
 
-ABI_VERSION = 3   # idealnerf_version(): 3 since idn_render_args carries `fused_march`
+ABI_VERSION = 4   # idealnerf_version(): 4 since idn_render_args carries `rng_mode / rng_seed / rng_ray0` (3: `fused_march`)
 
 # name -> (restype, argtypes); mirrors include/idealnerf.h one to one
 PROTOTYPES = {
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "idealnerf_frame_rays": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_int, C.c_int, fp, fp]),
     "idealnerf_to8b": (C.c_int, [fp, C.c_int64, C.c_int, fp, fp, fp]),
+    "idealnerf_philox_uniform": (C.c_int, [C.c_uint64, C.c_int, C.c_int64, C.c_int64, C.c_int, fp, fp]),
     "idealnerf_coarse_depths": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, fp, fp]),
     "idealnerf_composite_fwd": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.POINTER(CompositeOut), fp]),
     "idealnerf_sample_pdf_fwd": (C.c_int, [fp, fp, fp, C.c_int, C.c_int64, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp]),

@@ -8,6 +8,7 @@ is one C call into libidealnerf.so (coarse depths -> fused PE+MLP -> compositing
 inverse-CDF sampling -> merge -> fused PE+MLP -> compositing).
 """
 import logging
+import os
 
 import numpy as np
 import torch
@@ -29,6 +30,11 @@ def init_weights(m):
 
 
 class Network(nn.Module):
+    # True: perturb > 0 renders without autograd (the reference's default flags, also in eval) draw their random offsets inside
+    # the kernels instead of as torch.rand tensors (same distribution, this library's own numbers; see _render).  Opt-in:
+    # IDN_IN_KERNEL_DRAWS=1 (read once) or `net.in_kernel_draws = True`.
+    in_kernel_draws = os.environ.get("IDN_IN_KERNEL_DRAWS", "0") == "1"
+
     def __init__(self, H, W, focal, near, far, chunk, intrinsic, N_samlpes, N_importance, args: RenderConfig = None):
         super().__init__()
         # flags: an explicit RenderConfig, or -- the reference's unchanged constructor call -- the process's flags, which
@@ -154,7 +160,15 @@ class Network(nn.Module):
         else:
             n, dev = frame.nrows * frame.W, bc_rgb.device
         S, Ni = args.N_samples, args.N_importance
-        t_rand, u = self.draw_randoms(n, S, Ni, perturb, pytest, dev)
+        draws = None
+        if self.in_kernel_draws and perturb > 0. and not pytest:
+            # the frame's stratified offsets and importance draws are made INSIDE the kernels (idn_render_args.rng_mode): one seed
+            # per call from torch's CPU generator (so torch.manual_seed governs it, and equally seeded ranks rendering row bands of
+            # one frame draw from one table: a ray's row in it is its pixel index); no [n, S] / [n, Ni] random tensors exist
+            draws = (int(torch.randint(0, 2 ** 62, (1,)).item()), 0 if frame is None else frame.row0 * frame.W)
+            t_rand, u = None, None
+        else:
+            t_rand, u = self.draw_randoms(n, S, Ni, perturb, pytest, dev)
         from .helper import draw_sigma_noise
         # raw2outputs draws its noise per call, the coarse one first (baseline.py:353-361; numpy re-seeded each time under pytest)
         noise_c = draw_sigma_noise((n, S), raw_noise_std, pytest, dev)
@@ -169,7 +183,8 @@ class Network(nn.Module):
                                       fine.packed_weights() if Ni > 0 else None, ff,
                                       linspace01(S, dev), u, Ni, t_rand=t_rand, with_fg=with_fg, taps=taps or retraw,
                                       precision=coarse.prec_code, precision_fine=fine.prec_code if Ni > 0 else None,
-                                      lindisp=lindisp, white_bkgd=white_bkgd, noise_coarse=noise_c, noise_fine=noise_f, frame=frame)
+                                      lindisp=lindisp, white_bkgd=white_bkgd, noise_coarse=noise_c, noise_fine=noise_f, frame=frame,
+                                      draws=draws)
         ret = {'rgb_map': out['rgb_map'], 'disp_map': out['disp_map'], 'acc_map': out['acc_map']}
         if with_fg:
             ret['rgb_map_fg'] = out['rgb_fg']

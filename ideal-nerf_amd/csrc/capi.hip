@@ -86,7 +86,7 @@ using namespace idn;
 
 extern "C" {
 
-int idealnerf_version(void) { return 3; }   // 3: idn_render_args grew by `fused_march` (round 3)
+int idealnerf_version(void) { return 4; }   // 4: idn_render_args grew by `rng_mode / rng_seed / rng_ray0` (round 4); 3: by `fused_march`
 const char* idealnerf_last_error(void) { return g_err; }
 
 size_t idealnerf_packed_weight_floats(int precision) {
@@ -155,6 +155,14 @@ int idealnerf_frame_rays(const float* c2w, int H, int W, float focal, float cx, 
     if (H <= 0 || W <= 0 || row0 < 0 || nrows < 0 || row0 + nrows > H) return fail(IDN_EINVAL, "bad frame/rows");
     if (nrows == 0) return IDN_OK;
     return launch_frame_rays(c2w, H, W, focal, cx, cy, near_, far_, row0, nrows, rays_out, (hipStream_t)stream);
+}
+
+int idealnerf_philox_uniform(uint64_t seed, int which, int64_t row0, int64_t n_rows, int n_cols, float* out, void* stream) {
+    if (which != 0 && which != 1) return fail(IDN_EINVAL, "which %d (0 = stratified offsets, 1 = importance draws)", which);
+    if (row0 < 0 || n_rows < 0 || n_cols < 0) return fail(IDN_EINVAL, "bad sizes");
+    if (n_rows == 0 || n_cols == 0) return IDN_OK;
+    if (!out) return fail(IDN_EINVAL, "NULL pointer");
+    return launch_philox_uniform((unsigned long long)seed, which, row0, n_rows, n_cols, out, (hipStream_t)stream);
 }
 
 int idealnerf_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int lindisp, int64_t n_rays,
@@ -389,7 +397,10 @@ static int render_impl(const idn_render_args* a, const idn_frame* frame, void* s
     if (n == 0) return IDN_OK;
     if ((!a->rays && !frame) || !a->bc_rgb || !a->t_vals || !a->packed_coarse || !a->folded_coarse)
         return fail(IDN_EINVAL, "NULL input pointer");
-    if (Ni > 0 && (!a->packed_fine || !a->folded_fine || !a->u)) return fail(IDN_EINVAL, "fine pass inputs are NULL");
+    if (a->rng_mode != 0 && a->rng_mode != 1) return fail(IDN_EINVAL, "rng_mode %d (0 = t_rand / u as tensors, 1 = drawn in the kernels)", a->rng_mode);
+    if (a->rng_mode && (a->t_rand || a->u)) return fail(IDN_EINVAL, "rng_mode 1 draws t_rand and u in the kernels: both pointers must be NULL");
+    if (a->rng_mode && a->rng_ray0 < 0) return fail(IDN_EINVAL, "rng_ray0 < 0");
+    if (Ni > 0 && (!a->packed_fine || !a->folded_fine || (!a->u && !a->rng_mode))) return fail(IDN_EINVAL, "fine pass inputs are NULL");
     if (Ni > 0 && S < 3) return fail(IDN_EUNSUPPORTED, "importance sampling needs n_samples >= 3");
     const size_t need_base = idealnerf_render_workspace_bytes(n, S, Ni);
     const size_t need = need_base + (frame ? frame_scratch_bytes(n) : 0);
@@ -424,7 +435,8 @@ static int render_impl(const idn_render_args* a, const idn_frame* frame, void* s
                                              hipMemcpyDeviceToDevice, st));
         }
         const float* bc = a->bc_rgb + r0 * 3;
-        if (int e = launch_coarse_depths(rays, a->t_vals, off(a->t_rand, r0 * S), c, S, a->lindisp, w.z_c, st)) return e;
+        const Draws draws{(unsigned long long)a->rng_seed, (long)(a->rng_ray0 + r0), a->rng_mode};   // this pass's rows of the draw table
+        if (int e = launch_coarse_depths(rays, a->t_vals, off(a->t_rand, r0 * S), c, S, a->lindisp, w.z_c, st, draws)) return e;
         if (!a->fused_march)
             if (int e = launch_mlp(a->precision, a->packed_coarse, a->folded_coarse, nullptr, rays, w.z_c, nullptr, nullptr, c * S, S, w.raw_c, st)) return e;
         idn_composite_out co = {};
@@ -446,13 +458,13 @@ static int render_impl(const idn_render_args* a, const idn_frame* frame, void* s
             fo.weights = off(a->tap_weights_fine, r0 * Sf);
             fo.rgb_fg = off(a->rgb_fg, r0 * 3);
             fo.last_weight = off(a->last_weight, r0);
-            const float* u = a->u_per_ray ? a->u + r0 * Ni : a->u;
+            const float* u = a->u_per_ray ? off(a->u, r0 * Ni) : a->u;
             const bool split = a->fused_march == 2;   // two launches: the fine depths cross HBM (w.z_f), everything else stays on chip
             if (int e = launch_render_fused(a->fused_march, a->packed_coarse, a->folded_coarse, a->packed_fine, a->folded_fine, rays, bc, w.z_c,
                                             split ? w.z_f : nullptr, u, a->u_per_ray, c, a->white_bkgd, co, fo, off(a->z_std, r0),
                                             off(a->tap_raw_coarse, r0 * S * 4), off(a->tap_raw_fine, r0 * Sf * 4),
                                             split ? nullptr : off(a->tap_z_fine, r0 * Sf), off(a->tap_inds, r0 * Ni), off(a->tap_z_samples, r0 * Ni),
-                                            off(a->tap_cdf, r0 * (S - 1)), st))
+                                            off(a->tap_cdf, r0 * (S - 1)), st, draws))
                 return e;
             if (split)
                 if (int e = tap(off(a->tap_z_fine, r0 * Sf), w.z_f, (size_t)c * Sf * 4)) return e;
@@ -464,10 +476,10 @@ static int render_impl(const idn_render_args* a, const idn_frame* frame, void* s
             continue;
         }
         // the march between the passes: coarse compositing, inverse-CDF sampling and the merge in one kernel
-        const float* u = a->u_per_ray ? a->u + r0 * Ni : a->u;
+        const float* u = a->u_per_ray ? off(a->u, r0 * Ni) : a->u;
         if (int e = launch_march(w.raw_c, w.z_c, rays, bc, off(a->noise_coarse, r0 * S), a->white_bkgd, co, u, a->u_per_ray, c, S, Ni,
                                  off(a->tap_z_samples, r0 * Ni), off(a->tap_inds, r0 * Ni), off(a->tap_cdf, r0 * (S - 1)),
-                                 w.z_f, off(a->z_std, r0), st))
+                                 w.z_f, off(a->z_std, r0), st, draws))
             return e;
         if (int e = launch_mlp(prec_fine, a->packed_fine, a->folded_fine, nullptr, rays, w.z_f, nullptr, nullptr, c * Sf, Sf, w.raw_f, st)) return e;
         idn_composite_out fo = {};

@@ -73,7 +73,7 @@ int launch_frame_rays_pixels(const float* c2w_host, int H, int W, float focal, f
 // a3: coarse depths (audio_exp_nerf.py:306-330)
 // ---------------------------------------------------------------------------
 __global__ void coarse_depths_kernel(const float* rays, const float* t_vals, const float* t_rand, long n_rays, int S,
-                                     int lindisp, float* z) {
+                                     int lindisp, float* z, Draws draws) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_rays * S) return;
     const long r = idx / S;
@@ -85,21 +85,37 @@ __global__ void coarse_depths_kernel(const float* rays, const float* t_vals, con
         return near_ * (1.0f - t) + far_ * t;
     };
     float zz = zlin(s);
-    if (t_rand) {
+    if (t_rand || draws.on) {
         const float lower = (s == 0) ? zz : 0.5f * (zz + zlin(s - 1));
         const float upper = (s == S - 1) ? zz : 0.5f * (zlin(s + 1) + zz);
-        const float tr = (s == S - 1) ? 1.0f : t_rand[idx];
+        const float tr = (s == S - 1) ? 1.0f : draws.on ? draw_t_rand(draws, r, s) : t_rand[idx];
         zz = lower + (upper - lower) * tr;
     }
     z[idx] = zz;
 }
 
 int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays, int S,
-                         int lindisp, float* z, hipStream_t s) {
+                         int lindisp, float* z, hipStream_t s, Draws draws) {
     const long total = (long)n_rays * S;
     if (total <= 0) return IDN_OK;
     hipLaunchKernelGGL(coarse_depths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rays, t_vals,
-                       t_rand, (long)n_rays, S, lindisp, z);
+                       t_rand, (long)n_rays, S, lindisp, z, draws);
+    IDN_HIP_CHECK(hipGetLastError());
+    return IDN_OK;
+}
+
+// The table the in-kernel draws come from, as a tensor (include/idealnerf.h: idealnerf_philox_uniform)
+__global__ void philox_uniform_kernel(unsigned long long seed, int which, long row0, long n_rows, int n_cols, float* out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * n_cols) return;
+    const long r = idx / n_cols;
+    const int c = (int)(idx - r * n_cols);
+    out[idx] = philox_uniform(seed, 2ull * (unsigned long long)(row0 + r) + (unsigned long long)which, (unsigned)c);
+}
+int launch_philox_uniform(unsigned long long seed, int which, int64_t row0, int64_t n_rows, int n_cols, float* out, hipStream_t s) {
+    const long total = (long)n_rows * n_cols;
+    if (total <= 0) return IDN_OK;
+    hipLaunchKernelGGL(philox_uniform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, seed, which, (long)row0, (long)n_rows, n_cols, out);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;
 }
@@ -199,13 +215,13 @@ __global__ __launch_bounds__(256) void march_kernel(const float4* raw, const flo
 
 int launch_march(const float* raw, const float* z, const float* rays, const float* bc, const float* noise, int white_bkgd,
                  const idn_composite_out& out, const float* u, int u_per_ray, int64_t n_rays, int S, int Ni,
-                 float* z_samples, int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s) {
+                 float* z_samples, int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s, Draws draws) {
     if (n_rays <= 0) return IDN_OK;
     const int nb = S - 1;
     if (S < 3 || S > 64 * kMaxSpl || nb > kMaxBins - 1) return fail(IDN_EUNSUPPORTED, "march: n_samples %d outside [3, %d]", S, kMaxBins);
     if (Ni < 1 || Ni > kMaxNi) return fail(IDN_EUNSUPPORTED, "march: n_importance %d outside [1, %d]", Ni, kMaxNi);
     if (S + Ni > kMaxFine) return fail(IDN_EUNSUPPORTED, "march: n_samples + n_importance > %d", kMaxFine);
-    SampleArgs a{z, nullptr, nullptr, nullptr, u, u_per_ray, (long)n_rays, S, Ni, nb, z_samples, inds, cdf_out, z_fine, z_std};
+    SampleArgs a{z, nullptr, nullptr, nullptr, u, u_per_ray, (long)n_rays, S, Ni, nb, z_samples, inds, cdf_out, z_fine, z_std, draws};
     const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(raw);
     switch ((S + 63) / 64) {
@@ -227,7 +243,7 @@ int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in,
     if (Ni < 1 || Ni > kMaxNi) return fail(IDN_EUNSUPPORTED, "sample_pdf: n_importance %d outside [1, %d]", Ni, kMaxNi);
     if (S + Ni > kMaxFine) return fail(IDN_EUNSUPPORTED, "sample_pdf: n_samples + n_importance > %d", kMaxFine);
     if (z_fine && !z) return fail(IDN_EINVAL, "sample_pdf: the merged depths need the coarse depths z");
-    SampleArgs a{z, weights, cdf_in, bins_in, u, u_per_ray, (long)n_rays, S, Ni, nb, z_samples, inds, cdf_out, z_fine, z_std};
+    SampleArgs a{z, weights, cdf_in, bins_in, u, u_per_ray, (long)n_rays, S, Ni, nb, z_samples, inds, cdf_out, z_fine, z_std, Draws{0, 0, 0}};
     hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, s, a);
     IDN_HIP_CHECK(hipGetLastError());
     return IDN_OK;

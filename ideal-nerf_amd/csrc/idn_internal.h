@@ -218,20 +218,29 @@ int launch_audio_net_fwd(const idn_audio_net_params* p, const float* windows, in
 int launch_audio_net_bwd(const idn_audio_net_params* p, const idn_audio_net_grads* g, const float* windows, const float* saved,
                          const float* d_out, int n, hipStream_t s);
 int launch_to8b(const float* rgb, int64_t n_pixels, int swap_rb, unsigned char* out, int* flag, hipStream_t s);
+// In-kernel draws (include/idealnerf.h: rng_mode): row `ray0 + r` of the Philox table replaces t_rand[r, :] / u[r, :]
+struct Draws {
+    unsigned long long seed;
+    long ray0;
+    int on;
+};
+int launch_philox_uniform(unsigned long long seed, int which, int64_t row0, int64_t n_rows, int n_cols, float* out, hipStream_t s);
 int launch_coarse_depths(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays, int S,
-                         int lindisp, float* z, hipStream_t s);
+                         int lindisp, float* z, hipStream_t s, Draws draws = Draws{0, 0, 0});
 int launch_composite(const float* raw, const float* z, const float* rays, const float* bc, int64_t n_rays, int S,
                      const float* noise, int white_bkgd, const idn_composite_out& out, hipStream_t s);
 // coarse raw2outputs + sample_pdf + merge in one kernel (the weights stay on chip)
 int launch_march(const float* raw, const float* z, const float* rays, const float* bc, const float* noise, int white_bkgd,
                  const idn_composite_out& out, const float* u, int u_per_ray, int64_t n_rays, int S, int Ni,
-                 float* z_samples, int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s);
+                 float* z_samples, int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s,
+                 Draws draws = Draws{0, 0, 0});
 // render_fused.hip (fp32, S = 64, Ni = 128).  arrangement 1: coarse network -> march -> fine network -> compositing in ONE kernel;
 // 2: coarse network + march | fine network + compositing (two launches, the fine depths z_f[n, 192] cross HBM between them)
 int launch_render_fused(int arrangement, const float* packed_c, const float* folded_c, const float* packed_f, const float* folded_f,
                         const float* rays, const float* bc, const float* z_c, float* z_f, const float* u, int u_per_ray, int64_t n_rays,
                         int white_bkgd, const idn_composite_out& co, const idn_composite_out& fo, float* z_std, float* tap_raw_c,
-                        float* tap_raw_f, float* tap_z_fine, int64_t* tap_inds, float* tap_z_samples, float* tap_cdf, hipStream_t s);
+                        float* tap_raw_f, float* tap_z_fine, int64_t* tap_inds, float* tap_z_samples, float* tap_cdf, hipStream_t s,
+                        Draws draws = Draws{0, 0, 0});
 int launch_sample_pdf(const float* z, const float* weights, const float* cdf_in, const float* bins_in,
                       const float* u, int u_per_ray, int64_t n_rays, int S, int Ni, float* z_samples,
                       int64_t* inds, float* cdf_out, float* z_fine, float* z_std, hipStream_t s);

@@ -7,6 +7,29 @@ namespace idn {
 
 constexpr int kMaxSpl = 4;  // samples per lane: S <= 256
 
+// Column `col` of row `row` of the draw table (include/idealnerf.h: idealnerf_philox_uniform): Philox4x32-10 with
+// key = seed, counter = (col / 4, 0, row); word col % 4 as a 24-bit uniform on [0, 1).
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long row, unsigned col) {
+    unsigned c0 = col >> 2, c1 = 0u, c2 = (unsigned)row, c3 = (unsigned)(row >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const unsigned w = col & 3u;
+    const unsigned x = w == 0 ? c0 : w == 1 ? c1 : w == 2 ? c2 : c3;
+    return (float)(x >> 8) * 0x1p-24f;
+}
+__device__ __forceinline__ float draw_t_rand(const Draws& d, long ray, int s) { return philox_uniform(d.seed, 2ull * (unsigned long long)(d.ray0 + ray), (unsigned)s); }
+__device__ __forceinline__ float draw_u(const Draws& d, long ray, int j) { return philox_uniform(d.seed, 2ull * (unsigned long long)(d.ray0 + ray) + 1ull, (unsigned)j); }
+
 __device__ __forceinline__ double shfl_up_d(double v, int delta) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __shfl_up(lo, delta, 64);
@@ -170,6 +193,7 @@ struct SampleArgs {
     float* cdf_out;
     float* z_fine;
     float* z_std;
+    Draws draws;           // on: u is drawn here, row draws.ray0 + ray of the table (a.u is not read)
 };
 
 // torch.sum(x, -1) of a contiguous fp32 row as PyTorch's CPU kernel evaluates it (ATen
@@ -285,7 +309,7 @@ __device__ __forceinline__ void sample_pdf_ray(const SampleArgs& a, long ray, in
         const int i = ii * 64 + lane;
         zsv[ii] = 0.f;
         if (i < a.Ni) {
-            const float u = a.u_per_ray ? a.u[ray * a.Ni + i] : a.u[i];
+            const float u = a.draws.on ? draw_u(a.draws, ray, i) : a.u_per_ray ? a.u[ray * a.Ni + i] : a.u[i];
             int lo = 0, hi = nb;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;

@@ -61,6 +61,7 @@ struct FusedArgs {
     float* tap_z_samples;
     float* tap_cdf;
     float* z_f;          // [n, 192] fine depths in HBM: written by the coarse half, read by the fine half (split arrangement only)
+    Draws draws;         // on: the importance draws come from the Philox table instead of `u`
 };
 
 using WStreamDual = WStreamT<4, kSliceFrags, kRingSlots, true>;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
                     wrow[lane] = wts[0];
                     wave_lds_fence();
                     const SampleArgs sa{a.z_c, nullptr, nullptr, nullptr, a.u, a.u_per_ray, a.n_rays, kFS, kFNi, kFS - 1,
-                                        a.tap_z_samples, a.tap_inds, a.tap_cdf, kWhole ? a.tap_z_fine : a.z_f, a.z_std};
+                                        a.tap_z_samples, a.tap_inds, a.tap_cdf, kWhole ? a.tap_z_fine : a.z_f, a.z_std, a.draws};
                     sample_pdf_ray(sa, ray, lane, cdf, bins, val, wrow, zrow);
                 } else if constexpr (kWhole) {
                     for (int k = lane; k < kFSf; k += 64) zrow[k] = 0.0f;   // a padding ray: its points are computed and dropped
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(256, 1) void render_fused_kernel(FusedArgs a) {
 int launch_render_fused(int arrangement, const float* packed_c, const float* folded_c, const float* packed_f, const float* folded_f,
                         const float* rays, const float* bc, const float* z_c, float* z_f, const float* u, int u_per_ray, int64_t n_rays,
                         int white_bkgd, const idn_composite_out& co, const idn_composite_out& fo, float* z_std, float* tap_raw_c,
-                        float* tap_raw_f, float* tap_z_fine, int64_t* tap_inds, float* tap_z_samples, float* tap_cdf, hipStream_t s) {
+                        float* tap_raw_f, float* tap_z_fine, int64_t* tap_inds, float* tap_z_samples, float* tap_cdf, hipStream_t s,
+                        Draws draws) {
     if (n_rays <= 0) return IDN_OK;
     if (arrangement != 1 && arrangement != 2) return fail(IDN_EINVAL, "fused march: arrangement %d (1 = one kernel, 2 = coarse + march | fine + compositing)", arrangement);
     if (arrangement == 2 && !z_f) return fail(IDN_EINVAL, "fused march: the two-launch arrangement needs the fine-depth buffer z_f[n, 192]");
@@ -265,7 +267,7 @@ int launch_render_fused(int arrangement, const float* packed_c, const float* fol
     const int64_t ngroups = (n_rays + kFG - 1) / kFG;
     const int grid = (int)(ngroups < num_cu ? ngroups : num_cu);
     FusedArgs a{packed_c, folded_c, packed_f, folded_f, rays, bc, z_c, u, u_per_ray, (long)n_rays, white_bkgd, co, fo, z_std,
-                tap_raw_c, tap_raw_f, tap_z_fine, tap_inds, tap_z_samples, tap_cdf, z_f};
+                tap_raw_c, tap_raw_f, tap_z_fine, tap_inds, tap_z_samples, tap_cdf, z_f, draws};
     if (arrangement == 1) {
         ProfScope prof(s, n_rays * (kFS + kFSf), IDN_PROF_MLP_FWD);
         hipLaunchKernelGGL(render_fused_kernel<kFusedWhole>, dim3(grid), dim3(256), fused_lds<kFusedWhole>(), s, a);

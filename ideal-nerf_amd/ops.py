@@ -456,9 +456,19 @@ def make_frame(c2w, H, W, focal, near, far, row0=0, nrows=None, cx=None, cy=None
     return f
 
 
+def philox_uniform(seed, which, row0, n_rows, n_cols, device) -> torch.Tensor:
+    """Rows [row0, row0 + n_rows) of the table the in-kernel draws come from (`draws=` of render_rays_fwd) as a tensor:
+    which = 0 the stratified offsets t_rand, 1 the importance draws u (include/idealnerf.h: idealnerf_philox_uniform)."""
+    lib = _lib.load()
+    with _Launch(device=device) as L:   # (raises for a CPU device: there is no CPU path)
+        out = torch.empty((int(n_rows), int(n_cols)), dtype=torch.float32, device=L.device)
+        check(lib.idealnerf_philox_uniform(int(seed) & (2 ** 64 - 1), int(which), int(row0), int(n_rows), int(n_cols), _ptr(out, "out"), L.stream))
+    return out
+
+
 def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, n_importance,
                     t_rand=None, with_fg=False, taps=False, precision=IDN_PREC_F32, precision_fine=None, lindisp=False,
-                    white_bkgd=False, noise_coarse=None, noise_fine=None, fused=None, frame=None) -> Dict[str, torch.Tensor]:
+                    white_bkgd=False, noise_coarse=None, noise_fine=None, fused=None, frame=None, draws=None) -> Dict[str, torch.Tensor]:
     """Network.render_rays forward (audio_exp_nerf.py:297-371) as one C call.  `precision_fine` (default: the
     same as `precision`) selects the fine network's arithmetic; packed_f must be packed for it.
     `fused`: the arrangement of the kernels (same results bit for bit).  False / 0: the kernel sequence
@@ -469,8 +479,12 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
     built for fp32, 64 + 128 samples, no density noise -- anything else raises.  None: IDN_FUSED_MARCH (0 / 1 / 2, read once)
     wherever the fused kernel applies, else the sequence.
     `frame` (ops.make_frame) with `rays=None`: full-frame mode (idealnerf_render_frame_fwd) -- the ray records of the frame's
-    row band are derived on the device pass by pass; with `taps` they come back as `tap_rays`."""
+    row band are derived on the device pass by pass; with `taps` they come back as `tap_rays`.
+    `draws=(seed, ray0)` with `u=None, t_rand=None`: the perturb > 0 draws are made inside the kernels (rng_mode 1 of
+    idn_render_args), ray r using row ray0 + r of the table `philox_uniform` writes out -- no [n, S] / [n, Ni] random tensors."""
     lib = _lib.load()
+    if draws is not None and (u is not None or t_rand is not None):
+        raise IdealNerfError("draws=(seed, ray0) replaces BOTH t_rand and u: pass them as None")
     _shape(t_vals, "t_vals", None)
     if frame is not None:
         if rays is not None:
@@ -486,9 +500,10 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
     _shape(noise_fine, "noise_fine", n, S + Ni)
     _net_buffers(lib, packed_c, folded_c, precision, "_coarse")
     if Ni > 0:
-        if u is None or packed_f is None or folded_f is None:
-            raise IdealNerfError("n_importance > 0 needs u and the fine network's packed / folded buffers")
-        _u_shape(u, n, Ni)
+        if (u is None and draws is None) or packed_f is None or folded_f is None:
+            raise IdealNerfError("n_importance > 0 needs u (or draws=) and the fine network's packed / folded buffers")
+        if u is not None:
+            _u_shape(u, n, Ni)
         _net_buffers(lib, packed_f, folded_f, precision if precision_fine is None else precision_fine, "_fine")
     dev = bc_rgb.device
     with _Launch(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals, u, t_rand, noise_coarse, noise_fine) as L:
@@ -517,6 +532,8 @@ def render_rays_fwd(rays, bc_rgb, packed_c, folded_c, packed_f, folded_f, t_vals
         a.u_per_ray = 1 if (u is not None and u.dim() == 2) else 0
         a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
         a.noise_coarse, a.noise_fine = _ptr(noise_coarse, "noise_coarse"), _ptr(noise_fine, "noise_fine")
+        if draws is not None:
+            a.rng_mode, a.rng_seed, a.rng_ray0 = 1, int(draws[0]) & (2 ** 64 - 1), int(draws[1])
         if fused is None:
             applies = (S == 64 and Ni == 128 and noise_coarse is None and noise_fine is None and
                        _precision(precision) == IDN_PREC_F32 and (precision_fine is None or _precision(precision_fine) == IDN_PREC_F32))

@@ -217,8 +217,8 @@ typedef struct idn_render_args {
     const float* packed_fine;   /* may be NULL when n_importance == 0 */
     const float* folded_fine;
     const float* t_vals;  /* [n_samples] torch.linspace(0,1,N_samples) */
-    const float* t_rand;  /* [n, n_samples] or NULL (perturb == 0) */
-    const float* u;       /* [n_importance] (u_per_ray=0) or [n, n_importance] */
+    const float* t_rand;  /* [n, n_samples] or NULL (perturb == 0, or rng_mode == 1) */
+    const float* u;       /* [n_importance] (u_per_ray=0) or [n, n_importance]; NULL with rng_mode == 1 */
     int u_per_ray;
     /* outputs, any may be NULL */
     float* rgb_map;  float* disp_map;  float* acc_map;  float* depth_map;  float* last_weight;  float* rgb_fg;
@@ -256,7 +256,26 @@ typedef struct idn_render_args {
      * 1 and 2 give the sequence's results bit for bit; they are built for the fp32 arithmetic at n_samples = 64,
      * n_importance = 128 without density noise (anything else returns IDN_EUNSUPPORTED).  DESIGN.md section 3. */
     int fused_march;
+    /* The reference's perturb > 0 draws made inside the kernels instead of handed over as tensors ("optional
+     * t_rand / u buffers or Philox seed").  rng_mode = 1: t_rand and u must be NULL; ray r of this call (counted from rng_ray0, so
+     * that the chunks, row bands or ranks of one frame draw from ONE table whatever the partition) uses
+     *   t_rand[r, s] = idealnerf_philox_uniform's value (which = 0, row rng_ray0 + r, column s)   -- torch.rand(z_vals.shape),
+     *                                                                                                 audio_exp_nerf.py:314-326
+     *   u[r, j]      = ... (which = 1, row rng_ray0 + r, column j)                                 -- torch.rand(.., N_samples),
+     *                                                                                                 helper.py:283
+     * in the kernels that consume them (coarse depths; inverse CDF of the march / the fused ray kernel): no [n, S] / [n, Ni]
+     * random tensor exists.  Same distribution as torch.rand (24-bit uniform on [0, 1)); the NUMBERS are this library's own
+     * (upstream's CUDA generator is no contract either: its numbers depend on its launch geometry). */
+    int rng_mode;
+    uint64_t rng_seed;
+    int64_t rng_ray0;
 } idn_render_args;
+
+/* The table rng_mode = 1 draws from, as a tensor (for the stand-alone entries, which take t_rand / u as tensors, and for checking):
+ * out[r, c] (r < n_rows, c < n_cols) = the 24-bit uniform ((x >> 8) * 2^-24) of word c % 4 of Philox4x32-10 (Salmon et al., SC'11;
+ * ten rounds, multipliers 0xD2511F53 / 0xCD9E8D57, key increments 0x9E3779B9 / 0xBB67AE85) with key = (seed low, seed high) and
+ * counter = (c / 4, 0, low, high of 2 * (row0 + r) + which).  which: 0 = stratified offsets (t_rand), 1 = importance draws (u). */
+int idealnerf_philox_uniform(uint64_t seed, int which, int64_t row0, int64_t n_rows, int n_cols, float* out, void* stream);
 
 size_t idealnerf_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 int idealnerf_render_rays_fwd(const idn_render_args* a, void* stream);

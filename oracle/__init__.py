@@ -9,6 +9,9 @@ never imports this package and fails loudly when its HIP library is missing.
 Pinning status: PINNED.  Every function in ``render_oracle.py`` is checked
 against outputs of the reference itself (``/root/reference`` imported on CPU in
 the build container by ``tests/golden/make_golden.py``; vectors committed under
-``tests/golden/*.npz``) by ``tests/test_oracle_golden.py``.
+``tests/golden/*.npz``) by ``tests/test_oracle_golden.py``.  ``philox.py`` (the table of the library's in-kernel
+random draws -- the reference has no counterpart: it calls ``torch.rand``) is pinned by the generator's published
+known-answer vectors.
 """
+from . import philox  # noqa: F401
 from .render_oracle import *  # noqa: F401,F403

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(idn):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/idealnerf.h but not exported"
     assert sorted(idn._lib.PROTOTYPES) == names, "ctypes prototypes and header are out of sync"
-    assert lib.idealnerf_version() == 3
+    assert lib.idealnerf_version() == 4
     assert lib.idealnerf_folded_bias_floats() == 3136   # 2496 biases + alpha_linear (256) and rgb_linear (3 x 128) weight rows
     assert lib.idealnerf_packed_weight_floats(0) == 2304 * 256
     assert lib.idealnerf_packed_weight_floats(99) == 0
@@ -48,12 +48,13 @@ def test_ctypes_structs_match_c_layout(idn, tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "idealnerf.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(idn_facenerf_params), '
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(idn_facenerf_params), '
         'sizeof(idn_composite_out), sizeof(idn_render_args), offsetof(idn_facenerf_params, dim_aud), '
         'offsetof(idn_render_args, t_vals), offsetof(idn_render_args, tap_inds), '
         'offsetof(idn_render_args, workspace_bytes), offsetof(idn_render_args, precision_fine_plus1), '
         'sizeof(idn_frame), offsetof(idn_frame, focal), offsetof(idn_frame, rays_out), sizeof(idn_audio_net_params), '
-        'offsetof(idn_audio_net_params, dim_aud), sizeof(idn_audio_net_grads));return 0;}\n')
+        'offsetof(idn_audio_net_params, dim_aud), sizeof(idn_audio_net_grads), offsetof(idn_render_args, rng_mode), '
+        'offsetof(idn_render_args, rng_seed), offsetof(idn_render_args, rng_ray0));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
@@ -62,7 +63,8 @@ def test_ctypes_structs_match_c_layout(idn, tmp_path):
             L.FaceNerfParams.dim_aud.offset, L.RenderArgs.t_vals.offset, L.RenderArgs.tap_inds.offset,
             L.RenderArgs.workspace_bytes.offset, L.RenderArgs.precision_fine_plus1.offset,
             C.sizeof(L.Frame), L.Frame.focal.offset, L.Frame.rays_out.offset,
-            C.sizeof(L.AudioNetParams), L.AudioNetParams.dim_aud.offset, C.sizeof(L.AudioNetGrads)]
+            C.sizeof(L.AudioNetParams), L.AudioNetParams.dim_aud.offset, C.sizeof(L.AudioNetGrads),
+            L.RenderArgs.rng_mode.offset, L.RenderArgs.rng_seed.offset, L.RenderArgs.rng_ray0.offset]
     assert got == want
 
 
@@ -77,6 +79,22 @@ def test_c_abi_argument_errors_without_gpu(idn):
     a.precision = 7
     assert lib.idealnerf_render_rays_fwd(C.byref(a), None) == -2  # IDN_EUNSUPPORTED
     assert lib.idealnerf_render_workspace_bytes(0, 64, 128) == 0
+    # in-kernel draws: the mode is validated, and it excludes the tensors it replaces
+    a = idn._lib.RenderArgs()
+    a.n_rays, a.n_samples, a.n_importance = 4, 64, 128
+    a.bc_rgb = a.t_vals = a.packed_coarse = a.folded_coarse = a.packed_fine = a.folded_fine = a.rays = 1
+    a.rng_mode = 2
+    assert lib.idealnerf_render_rays_fwd(C.byref(a), None) == -1 and b"rng_mode" in lib.idealnerf_last_error()
+    a.rng_mode, a.u = 1, 1
+    assert lib.idealnerf_render_rays_fwd(C.byref(a), None) == -1 and b"must be NULL" in lib.idealnerf_last_error()
+    a.u, a.rng_ray0 = None, -1
+    assert lib.idealnerf_render_rays_fwd(C.byref(a), None) == -1 and b"rng_ray0" in lib.idealnerf_last_error()
+    a.rng_ray0 = 0   # (draws on, no u: accepted up to the next check, the workspace)
+    assert lib.idealnerf_render_rays_fwd(C.byref(a), None) == -4 and b"workspace" in lib.idealnerf_last_error()
+    assert lib.idealnerf_philox_uniform(1, 2, 0, 4, 4, None, None) == -1 and b"which" in lib.idealnerf_last_error()
+    assert lib.idealnerf_philox_uniform(1, 0, -1, 4, 4, None, None) == -1
+    assert lib.idealnerf_philox_uniform(1, 0, 0, 4, 4, None, None) == -1 and b"NULL" in lib.idealnerf_last_error()
+    assert lib.idealnerf_philox_uniform(1, 0, 0, 0, 4, None, None) == 0
     # AudioNet kernels: NULL parameters, a dim_aud the kernel is not built for and more windows than the backward holds in LDS
     ap = idn._lib.AudioNetParams()
     assert lib.idealnerf_audio_net_fwd(C.byref(ap), None, 1, None, None, None) == -1 and b"NULL" in lib.idealnerf_last_error()

@@ -1611,6 +1611,109 @@ def test_fused_ray_kernel_equals_the_unfused_path(idn, dev, n_rays, jitter, with
         idn.ops.render_rays_fwd(r, bc, pk_c, fold_c(*cond), pk_f, fold_f(*cond), torch.linspace(0.0, 1.0, 32).to(dev), u, 128, fused=True)
 
 
+def test_philox_table_matches_the_cpu_restatement(idn, dev):
+    """The table the in-kernel draws come from (idealnerf_philox_uniform) against oracle/philox.py -- itself pinned by
+    Philox4x32-10's published known-answer vectors -- bit for bit: both tables, ragged widths, a row offset beyond 32 bits."""
+    from oracle import philox
+    for seed, which, row0, n, cols in [(0, 0, 0, 7, 64), (0x0123456789ABCDEF, 1, 0, 129, 128), (2 ** 64 - 1, 1, 32768, 40, 61),
+                                       (12345, 0, (1 << 33) + 5, 16, 5), (99, 1, 0, 1, 1)]:
+        got = idn.ops.philox_uniform(seed, which, row0, n, cols, dev)
+        want = torch.from_numpy(philox.uniform_table(seed, which, row0, n, cols))
+        assert got.shape == want.shape and torch.equal(got.cpu(), want), (seed, which, row0, n, cols)
+    assert idn.ops.philox_uniform(1, 0, 0, 0, 64, dev).shape == (0, 64)
+
+
+@pytest.mark.parametrize("n_rays,ray0", [(5, 0), (1031, 77), (40000, 3)])
+def test_in_kernel_draws_equal_the_same_draws_as_tensors(idn, dev, n_rays, ray0):
+    """perturb > 0 with the draws made INSIDE the kernels (idn_render_args.rng_mode = 1: stratified offsets in the coarse-depth
+    kernel, importance draws in the march) against the same render fed the table as t_rand / u tensors -- written by the CPU
+    restatement of the generator: every output and every tap BIT FOR BIT, in all three kernel arrangements, across the
+    library's internal 32 768-ray passes (40 000 rays: the second pass must continue at row ray0 + 32 768).  The tensor path
+    itself is pinned to the reference under jitter by `test_render_rays_golden_jitter` / `rays64_jitter.npz`."""
+    from oracle import philox
+    dims, pc, pf, (pk_c, fold_c), (pk_f, fold_f) = _nets(idn, dev)
+    syn = oracle.synthetic_frame(48, 48, seed=7, dims=dims)
+    rays = idn.ops.frame_rays(syn["c2w"], 48, 48, syn["focal"], NEAR, FAR, device=dev)
+    sel = torch.from_numpy(np.random.RandomState(n_rays).choice(48 * 48, n_rays, replace=n_rays > 48 * 48))
+    r = rays[sel.to(dev)].contiguous()
+    bc = syn["bc"].reshape(-1, 3)[sel].contiguous().to(dev)
+    cond = (syn["aud"], syn["expr"], syn["latent"])
+    t = torch.linspace(0.0, 1.0, 64).to(dev)
+    seed = 0x5DEECE66D + n_rays
+    t_rand = torch.from_numpy(philox.uniform_table(seed, 0, ray0, n_rays, 64)).to(dev)
+    u = torch.from_numpy(philox.uniform_table(seed, 1, ray0, n_rays, 128)).to(dev)
+    nets = (pk_c, fold_c(*cond), pk_f, fold_f(*cond), t)
+    taps = n_rays < 2000
+    for how in (False, True, "split"):
+        ten = idn.ops.render_rays_fwd(r, bc, *nets, u, 128, t_rand=t_rand, taps=taps, with_fg=True, fused=how)
+        drw = idn.ops.render_rays_fwd(r, bc, *nets, None, 128, taps=taps, with_fg=True, fused=how, draws=(seed, ray0))
+        assert sorted(ten) == sorted(drw)
+        for k in ten:
+            assert torch.isfinite(ten[k].float()).all(), k
+            assert torch.equal(ten[k], drw[k]), f"{k} (fused={how!r}): in-kernel draws != the table as tensors"
+    if taps:   # the draws did move the samples: against the deterministic render the depths differ
+        det = idn.ops.render_rays_fwd(r, bc, *nets, torch.linspace(0.0, 1.0, 128).to(dev), 128, taps=True)
+        assert not torch.equal(det["tap_z_coarse"], drw["tap_z_coarse"]) and not torch.equal(det["tap_z_samples"], drw["tap_z_samples"])
+    # coarse-only renders draw their offsets the same way; the draws replace BOTH tensors
+    c_t = idn.ops.render_rays_fwd(r, bc, pk_c, nets[1], None, None, t, None, 0, t_rand=t_rand)
+    c_d = idn.ops.render_rays_fwd(r, bc, pk_c, nets[1], None, None, t, None, 0, draws=(seed, ray0))
+    assert all(torch.equal(c_t[k], c_d[k]) for k in c_t)
+    with pytest.raises(idn._lib.IdealNerfError, match="replaces BOTH"):
+        idn.ops.render_rays_fwd(r, bc, *nets, u, 128, draws=(seed, ray0))
+
+
+def test_in_kernel_draws_in_frame_mode_do_not_depend_on_the_partition(idn, dev):
+    """Full-frame mode with in-kernel draws: a ray's row of the draw table is its pixel index, so a frame rendered as one band,
+    as two uneven bands (what two ranks would do) or from materialised ray records with the table as tensors is the same frame
+    bit for bit; and the module path (`net.in_kernel_draws = True`, the reference's default perturb = 1 in eval) renders
+    exactly that frame for the seed it drew from torch's CPU generator."""
+    from oracle import philox
+    dims, pc, pf, (pk_c, fold_c), (pk_f, fold_f) = _nets(idn, dev)
+    H = W = 40
+    syn = oracle.synthetic_frame(H, W, seed=3, dims=dims)
+    cond = (syn["aud"], syn["expr"], syn["latent"])
+    t = torch.linspace(0.0, 1.0, 64).to(dev)
+    nets = (pk_c, fold_c(*cond), pk_f, fold_f(*cond), t)
+    bc = syn["bc"].reshape(H, W, 3).to(dev)
+    seed = 424242
+    whole = idn.ops.render_rays_fwd(None, bc.reshape(-1, 3), *nets, None, 128, draws=(seed, 0),
+                                    frame=idn.ops.make_frame(syn["c2w"], H, W, syn["focal"], NEAR, FAR))
+    parts = []
+    for row0, nrows in ((0, 13), (13, 27)):
+        f = idn.ops.make_frame(syn["c2w"], H, W, syn["focal"], NEAR, FAR, row0, nrows)
+        parts.append(idn.ops.render_rays_fwd(None, bc[row0:row0 + nrows].reshape(-1, 3).contiguous(), *nets, None, 128, draws=(seed, row0 * W), frame=f))
+    rays = idn.ops.frame_rays(syn["c2w"], H, W, syn["focal"], NEAR, FAR, device=dev)
+    ten = idn.ops.render_rays_fwd(rays, bc.reshape(-1, 3), *nets, torch.from_numpy(philox.uniform_table(seed, 1, 0, H * W, 128)).to(dev), 128,
+                                  t_rand=torch.from_numpy(philox.uniform_table(seed, 0, 0, H * W, 64)).to(dev))
+    for k in whole:
+        assert torch.equal(whole[k], torch.cat([p[k] for p in parts], 0)), k
+        assert torch.equal(whole[k], ten[k]), k
+    # the module path: render_dynamic_face in eval mode with the reference's default flags (perturb = 1, helper.py:70)
+    from idealnerf_amd.audio_exp_nerf import Network
+    from idealnerf_amd.helper import RenderConfig
+    net = Network(H, W, syn["focal"], NEAR, FAR, 512, None, 64, 128, args=RenderConfig(perturb=1.0, chunk=512, near=NEAR, far=FAR)).to(dev)
+    net.face_nerf_coarse.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(2, dims)))
+    net.face_nerf_fine.load_state_dict(scale_sigma(oracle.xavier_facenerf_params(3, dims)))
+    net.eval()
+    assert net.in_kernel_draws is False        # opt-in
+    net.in_kernel_draws = True
+    call = lambda: net.render_dynamic_face(H, W, syn["focal"], expr=syn["expr"].to(dev), poses=syn["c2w"], latent_code=syn["latent"].to(dev),
+                                           render_poses=syn["c2w"][:3, :4], chunk=512, near=NEAR, far=FAR, bc_rgb=bc, aud_para=syn["aud"].to(dev))
+    torch.manual_seed(5)
+    seed_net = int(torch.randint(0, 2 ** 62, (1,)).item())
+    torch.manual_seed(5)
+    with torch.no_grad():
+        rgb = call()[0]
+        again = call()[0]          # the next call draws the next seed: another frame of the same distribution
+    cd = tuple(v.to(dev) for v in cond)
+    c, f = net.face_nerf_coarse, net.face_nerf_fine
+    want = idn.ops.render_rays_fwd(None, bc.reshape(-1, 3), c.packed_weights(), c.folded_bias(cd[0], cd[1], cd[2]), f.packed_weights(),
+                                   f.folded_bias(cd[0], cd[1], cd[2]), t, None, 128, precision=c.prec_code, draws=(seed_net, 0),
+                                   frame=idn.ops.make_frame(syn["c2w"], H, W, syn["focal"], NEAR, FAR))
+    assert torch.equal(rgb.reshape(-1, 3), want["rgb_map"])
+    assert not torch.equal(again, rgb) and float((again - rgb).abs().mean()) < 0.05
+
+
 def test_train_forward_defines_every_row_of_the_activation_slab(idn, dev):
     """The weight-gradient GEMMs contract over all p_pad rows of the saved activations, so the padding
     rows of a ragged pass must hold finite numbers (their deltas are zero, but 0 x NaN is not): fill

@@ -296,3 +296,31 @@ def test_bf16_rounding_model_is_the_reference_network_with_rounded_operands(gold
     assert np.median(e) < 2e-6 and (e > 1e-4).mean() < 0.02 and e.max() < 5e-3, (np.median(e), (e > 1e-4).mean(), e.max())
     vs_ref = float((emu - T(g[name + "_out"]).double()).abs().max() / scale)
     assert 1e-3 < vs_ref < 2e-2, vs_ref
+
+
+def test_philox_known_answers():
+    """oracle/philox.py against the known-answer vectors of Philox4x32-10 (Random123 kat_vectors)."""
+    from oracle import philox
+    for counter, key, expect in philox.KNOWN_ANSWERS:
+        got = philox.philox4x32_10(counter, key)
+        assert tuple(int(x) for x in got) == expect
+
+
+def test_philox_table_layout_and_distribution():
+    """The table the in-kernel draws come from: word w of block b is column 4 b + w, rows 2 r / 2 r + 1 are a ray's offsets /
+    importance draws, a sub-table is a slice of the table (what lets chunks and row bands draw consistently), and the values
+    are 24-bit uniforms on [0, 1) like torch.rand's."""
+    from oracle import philox
+    seed = 0x0123456789ABCDEF
+    t = philox.uniform_table(seed, 0, 0, 64, 64)
+    u = philox.uniform_table(seed, 1, 0, 64, 128)
+    w = philox.philox4x32_10((3, 0, 2 * 5 + 1, 0), (seed & 0xFFFFFFFF, seed >> 32))
+    assert u[5, 12:16].tolist() == [np.float32(int(x) >> 8) * np.float32(2.0 ** -24) for x in w]
+    assert np.array_equal(philox.uniform_table(seed, 1, 40, 24, 128), u[40:])
+    assert np.array_equal(philox.uniform_table(seed, 0, 0, 64, 61), t[:, :61])        # ragged widths: a prefix of the row
+    assert not np.array_equal(t[:, :64], u[:, :64]) and not np.array_equal(philox.uniform_table(seed + 1, 0, 0, 64, 64), t)
+    big = philox.uniform_table(7, 1, 1 << 33, 4096, 128)                               # rows beyond 32 bits
+    assert big.dtype == np.float32 and big.min() >= 0.0 and big.max() < 1.0
+    assert np.array_equal(big * 2 ** 24, np.floor(big * 2 ** 24))
+    assert abs(float(big.mean()) - 0.5) < 2e-3 and abs(float(big.var()) - 1 / 12) < 1e-3
+    assert len(np.unique(big)) > 0.98 * big.size
