@@ -467,7 +467,19 @@ __device__ __forceinline__ void x6_retire(X6Frag (&f)[3]) {
 }
 
 // One 256 x 256 product (one split of the points) of the batch below.
+#ifdef IDN_DIAG_X6   // diagnostic build only: where a chunk of the bf16-piece dW GEMM spends its cycles (tools/diag_tn_x6.py)
+__device__ unsigned long long g_x6_diag[8];   // row 0, rows 1..3 up to the barrier, barrier, tail, prologue + epilogue, chunks, workgroups
+// s_memtime returns through lgkmcnt, which the kernel counts by hand for its LDS reads: the stamp waits for itself on the spot,
+// at points where no counted read is younger than what the code is about to wait for anyway
+#define X6_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#else
+#define X6_STAMP(v)
+#endif
 __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split, char* x6_smem) {
+#ifdef IDN_DIAG_X6
+    unsigned long long dx_t0 = 0, dx_a = 0, dx_b = 0, dx_c = 0, dx_d = 0, dx_row0 = 0, dx_rows = 0, dx_bar = 0, dx_tail = 0, dx_loop0 = 0, dx_loop1 = 0;
+    X6_STAMP(dx_t0);
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hh = lane >> 5;
@@ -567,8 +579,10 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
         });
     };
     if (IDN_X6_EARLY_BARRIER) issue_first_row(a_base, b_base);
+    X6_STAMP(dx_loop0);
 #pragma unroll 1
     for (int rc = 0; rc < n_chunks; ++rc) {
+        X6_STAMP(dx_a);
         const int buf = rc & 1;
         const uint32_t pa = a_base + buf * kX6BufBytes, pb = b_base + buf * kX6BufBytes;
         // issue order = consumption order: row 0 (nine of its reads are already in flight), then the other delta tiles
@@ -601,6 +615,7 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
         x6_retire<0>(fa[1]);
         x6_retire<0>(fa[2]);
         x6_retire<0>(fa[3]);
+        X6_STAMP(dx_b);
         // Rows 1..3: 72 MFMAs, each followed by one SLICE of the side work (the next chunk's split + store, the reloads
         // with the chunk after it) and a scheduling fence: at most ~6 vector instructions, two loads or one store behind
         // an MFMA that occupies the pipe for 32 cycles.  (Left alone, hipcc issues 40 MFMAs back to back and then 50
@@ -614,19 +629,31 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
         char* const dst = my_slot + (buf ^ 1) * kX6BufBytes;
         unsigned pw[2][3][8];
         float t0 = 0.f, t1 = 0.f;
+        // Timing-only experiments (WRONG results), -DIDN_X6_TIMING_DROP=<bits>: 1 drops the split arithmetic of the slices, 2 their LDS
+        // stores, 4 their reloads -- which part of the side work costs the matrix pipe its idle cycles (profiles/HISTORY.md, round 4)
+#ifndef IDN_X6_TIMING_DROP
+#define IDN_X6_TIMING_DROP 0
+#endif
         auto slice = [&](auto X_, auto S_) {
             constexpr int X = decltype(X_)::value, sl = decltype(S_)::value;
             float (&r)[kTnRows] = *(X ? &rb : &ra);
             auto store = [&](auto Q_, auto H_) {
                 constexpr int q = decltype(Q_)::value, h2 = decltype(H_)::value;
+                if constexpr (IDN_X6_TIMING_DROP & 2) return;
                 *reinterpret_cast<tn_u32x4*>(dst + X * (8 * 3 * kFragBytes) + q * kFragBytes + h2 * 512) =
                     tn_u32x4{pw[X][q][4 * h2], pw[X][q][4 * h2 + 1], pw[X][q][4 * h2 + 2], pw[X][q][4 * h2 + 3]};
             };
             if constexpr (sl < 24) {
                 constexpr int j = sl / 3, ph = sl % 3;
-                if constexpr (ph == 0) {
+                if constexpr (ph == 0 && (IDN_X6_TIMING_DROP & 1)) {
+                    if constexpr (!(IDN_X6_TIMING_DROP & 4)) asm volatile("s_waitcnt vmcnt(30)" : "+v"(r[2 * j]), "+v"(r[2 * j + 1])::"memory");
+                    pw[X][0][j] = __float_as_uint(r[2 * j]);
+                    pw[X][1][j] = __float_as_uint(r[2 * j + 1]);
+                    pw[X][2][j] = __float_as_uint(r[2 * j]);
+                } else if constexpr (ph == 1 && (IDN_X6_TIMING_DROP & 1)) {
+                } else if constexpr (ph == 0) {
                     // rows 2 j, 2 j + 1 of the chunk being split have landed: 30 younger loads may still be in flight
-                    asm volatile("s_waitcnt vmcnt(30)" : "+v"(r[2 * j]), "+v"(r[2 * j + 1])::"memory");
+                    if constexpr (!(IDN_X6_TIMING_DROP & 4)) asm volatile("s_waitcnt vmcnt(30)" : "+v"(r[2 * j]), "+v"(r[2 * j + 1])::"memory");
                     const unsigned p1 = tn_cvt_pk_bf16(r[2 * j], r[2 * j + 1]);
                     pw[X][0][j] = p1;
                     t0 = r[2 * j] - __uint_as_float(p1 << 16);
@@ -645,8 +672,10 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
                     t1 = t1 - __uint_as_float(p2 & 0xffff0000u);
                     pw[X][2][j] = tn_cvt_pk_bf16(t0, t1);
                 } else {
-                    load_row_at(r[2 * j], X ? rsrcB : rsrcA, (nbase + 2 * j) * (X ? rowB : rowA), X ? voffB : voff);
-                    load_row_at(r[2 * j + 1], X ? rsrcB : rsrcA, (nbase + 2 * j + 1) * (X ? rowB : rowA), X ? voffB : voff);
+                    if constexpr (!(IDN_X6_TIMING_DROP & 4)) {
+                        load_row_at(r[2 * j], X ? rsrcB : rsrcA, (nbase + 2 * j) * (X ? rowB : rowA), X ? voffB : voff);
+                        load_row_at(r[2 * j + 1], X ? rsrcB : rsrcA, (nbase + 2 * j + 1) * (X ? rowB : rowA), X ? voffB : voff);
+                    }
                     if constexpr (j >= 3 && j < 6) store(ic_<j - 3>{}, ic_<0>{});
                     if constexpr (j == 7) store(ic_<0>{}, ic_<1>{});
                 }
@@ -670,8 +699,15 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
                 // everyone's pieces of chunk rc + 1 are in LDS; everyone has read chunk rc's (all 24 fragment reads were retired
                 // before row 1): the chunk barrier, twelve MFMAs early, and behind it the first row of the next chunk
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                X6_STAMP(dx_c);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                X6_STAMP(dx_d);
+#ifdef IDN_DIAG_X6
+                dx_row0 += dx_b - dx_a;
+                dx_rows += dx_c - dx_b;
+                dx_bar += dx_d - dx_c;
+#endif
                 issue_first_row(a_base + (buf ^ 1) * kX6BufBytes, b_base + (buf ^ 1) * kX6BufBytes);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -682,6 +718,11 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
+#ifdef IDN_DIAG_X6
+        X6_STAMP(dx_a);            // (the first-row reads of the next chunk, issued twelve MFMAs ago, are waited for here)
+        dx_tail += dx_a - dx_d;
+        dx_loop1 = dx_a;
+#endif
     }
     if (IDN_X6_EARLY_BARRIER) {   // the first-row reads issued behind the last chunk's barrier (of a chunk that does not exist): retired, never used
         x6_retire<0>(fa[0]);
@@ -702,6 +743,21 @@ __device__ __forceinline__ void gemm_tn_x6_item(const TNArgs& g, const int split
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 out[(long)(32 * (4 * wr + x) + d_row(r, hh)) * g.K + 32 * (4 * wc + y) + i] = acc[x][y][r];
+#ifdef IDN_DIAG_X6
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long dx_t1;
+    X6_STAMP(dx_t1);
+    if (tid == 0) {
+        atomicAdd(&g_x6_diag[0], dx_row0);
+        atomicAdd(&g_x6_diag[1], dx_rows);
+        atomicAdd(&g_x6_diag[2], dx_bar);
+        atomicAdd(&g_x6_diag[3], dx_tail);
+        atomicAdd(&g_x6_diag[4], (dx_t1 - dx_t0) - (dx_loop1 - dx_loop0));
+        atomicAdd(&g_x6_diag[5], (unsigned long long)n_chunks);
+        atomicAdd(&g_x6_diag[6], 1ull);
+        atomicAdd(&g_x6_diag[7], dx_t1 - dx_t0);
+    }
+#endif
 }
 // The 256 x 256 weight-gradient products of a pass as ONE launch, ONE PRODUCT PER WORKGROUP: workgroup z works on item
 // z / splits over split z % splits of the points, with splits = 2 #CUs / #items (56 for the nine products of a pass on 256 CUs).
@@ -1299,6 +1355,14 @@ int launch_pass_bwd(const idn_facenerf_params& p, const idn_facenerf_grads& gr, 
     return IDN_OK;
 }
 
+#ifdef IDN_DIAG_X6
+extern "C" int idealnerf_diag_x6_read(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x6_diag), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_x6_diag), z, sizeof(z)) != hipSuccess) return -3;
+    return 0;
+}
+#endif
 #ifdef IDN_DIAG
 extern "C" int idealnerf_diag_tn_read(unsigned long long* out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tn_diag), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
