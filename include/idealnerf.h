@@ -271,7 +271,8 @@ typedef struct idn_render_args {
     int64_t rng_ray0;
 } idn_render_args;
 
-/* The table rng_mode = 1 draws from, as a tensor (for the stand-alone entries, which take t_rand / u as tensors, and for checking):
+/* The table rng_mode = 1 draws from, as a tensor -- stands where upstream calls torch.rand for `t_rand` (audio_exp_nerf.py:314-326)
+ * and `u` (helper.py:283); for the stand-alone entries, which take t_rand / u as tensors, and for checking:
  * out[r, c] (r < n_rows, c < n_cols) = the 24-bit uniform ((x >> 8) * 2^-24) of word c % 4 of Philox4x32-10 (Salmon et al., SC'11;
  * ten rounds, multipliers 0xD2511F53 / 0xCD9E8D57, key increments 0x9E3779B9 / 0xBB67AE85) with key = (seed low, seed high) and
  * counter = (c / 4, 0, low, high of 2 * (row0 + r) + which).  which: 0 = stratified offsets (t_rand), 1 = importance draws (u). */
